@@ -1,0 +1,154 @@
+// Initial states.  API parity with ya||a `include/inits.cuh` for the functions
+// on or next to the step path: random_disk (:14-31), random_sphere (:33-51),
+// random_cuboid (:53-75), relu_force (:78-93), relaxed_sphere (:95-125),
+// relaxed_cuboid (:127-155).  Each random_* takes an optional trailing `seed`
+// (0 = seed from std::random_device, the reference's behaviour) so runs can be
+// reproduced; draws use glibc rand() in the reference's order and arithmetic.
+#pragma once
+
+#include <assert.h>
+#include <math.h>
+#include <stdlib.h>
+
+#include <iostream>
+#include <random>
+
+#include "dtypes.cuh"
+
+template<typename Pt, template<typename> class Solver>
+class Solution;
+
+namespace ya {
+inline void seed_rand(unsigned seed)
+{
+    if (seed == 0) {
+        std::random_device rd;
+        seed = rd();
+    }
+    srand(seed);
+}
+inline double unit_rand() { return rand() / (RAND_MAX + 1.); }
+}  // namespace ya
+
+
+template<typename Pt, template<typename> class Solver>
+void random_disk(float dist_to_nb, Solution<Pt, Solver>& points, unsigned int n_0 = 0,
+    unsigned seed = 0)
+{
+    assert(n_0 < *points.h_n);
+    ya::seed_rand(seed);
+    // Radius based on hexagonal lattice
+    const double r_max = pow((*points.h_n - n_0) / 0.9069, 1. / 2) * dist_to_nb / 2;
+    for (unsigned i = n_0; i < (unsigned)*points.h_n; i++) {
+        const double r = r_max * pow(ya::unit_rand(), 1. / 2);
+        const double phi = ya::unit_rand() * 2 * M_PI;
+        points.h_X[i].x = 0;
+        points.h_X[i].y = r * sin(phi);
+        points.h_X[i].z = r * cos(phi);
+    }
+    points.copy_to_device();
+}
+
+template<typename Pt, template<typename> class Solver>
+void random_sphere(float dist_to_nb, Solution<Pt, Solver>& points, unsigned int n_0 = 0,
+    unsigned seed = 0)
+{
+    assert(n_0 < *points.h_n);
+    ya::seed_rand(seed);
+    // Radius based on random sphere packing
+    const double r_max = pow((*points.h_n - n_0) / 0.64, 1. / 3) * dist_to_nb / 2;
+    for (unsigned i = n_0; i < (unsigned)*points.h_n; i++) {
+        const double r = r_max * pow(ya::unit_rand(), 1. / 3);
+        const double theta = acos(2. * rand() / (RAND_MAX + 1.) - 1);
+        const double phi = ya::unit_rand() * 2 * M_PI;
+        points.h_X[i].x = r * sin(theta) * cos(phi);
+        points.h_X[i].y = r * sin(theta) * sin(phi);
+        points.h_X[i].z = r * cos(theta);
+    }
+    points.copy_to_device();
+}
+
+template<typename Pt, template<typename> class Solver>
+void random_cuboid(float dist_to_nb, float3 minimum, float3 maximum,
+    Solution<Pt, Solver>& points, unsigned int n_0 = 0, unsigned seed = 0)
+{
+    assert(n_0 < *points.h_n);
+
+    const float3 dimension = maximum - minimum;
+    const auto cube_volume = dimension.x * dimension.y * dimension.z;
+    const auto sphere_volume = 4. / 3 * M_PI * pow(dist_to_nb / 2, 3);
+    const auto n = cube_volume / sphere_volume * 0.64;  // Sphere packing
+
+    assert(n_0 + n < *points.h_n);
+    *points.h_n = n_0 + n;
+
+    ya::seed_rand(seed);
+    for (unsigned i = n_0; i < (unsigned)*points.h_n; i++) {
+        points.h_X[i].x = minimum.x + dimension.x * ya::unit_rand();
+        points.h_X[i].y = minimum.y + dimension.y * ya::unit_rand();
+        points.h_X[i].z = minimum.z + dimension.z * ya::unit_rand();
+    }
+    points.copy_to_device();
+}
+
+
+// Repulsion below 0.8, attraction up to 1 (inits.cuh:78-93).
+template<typename Pt>
+__device__ Pt relu_force(Pt Xi, Pt r, float dist, int i, int j)
+{
+    Pt dF{0};
+
+    if (i == j) return dF;
+
+    if (dist > 1.f) return dF;
+
+    auto F = fmaxf(0.8f - dist, 0) * 2.f - fmaxf(dist - 0.8f, 0);
+    dF.x = r.x * F / dist;
+    dF.y = r.y * F / dist;
+    dF.z = r.z * F / dist;
+
+    return dF;
+}
+
+namespace ya {
+template<typename Pt, template<typename> class Solver>
+void relax_and_rescale(
+    double scale, Solution<Pt, Solver>& points, int steps, int warn_above)
+{
+    if (*points.h_n > warn_above)
+        std::cout << "Warning: The system is quite large, it may "
+                  << "not be completely relaxed." << std::endl;
+    for (int i = 0; i < steps; i++) points.template take_step<relu_force>(0.1f);
+    points.copy_to_host();
+    for (int i = 0; i < *points.h_n; i++) {
+        points.h_X[i].x *= scale;
+        points.h_X[i].y *= scale;
+        points.h_X[i].z *= scale;
+    }
+    points.copy_to_device();
+}
+}  // namespace ya
+
+// Random sphere at spacing 0.6 relaxed with relu_force (equilibrium 0.8), then
+// rescaled to dist_to_nb (inits.cuh:95-125).
+template<typename Pt, template<typename> class Solver>
+void relaxed_sphere(float dist_to_nb, Solution<Pt, Solver>& points, unsigned int n_0 = 0,
+    unsigned seed = 0)
+{
+    random_sphere(0.6, points, n_0, seed);
+    const int n = *points.h_n;
+    const int steps = n <= 100 ? 500 : (n <= 1000 ? 1000 : (n <= 6000 ? 2000 : 3000));
+    ya::relax_and_rescale(dist_to_nb / 0.8, points, steps, 10000);
+}
+
+// Same in a box; the box is shrunk by the final scale first (inits.cuh:127-155).
+template<typename Pt, template<typename> class Solver>
+void relaxed_cuboid(float dist_to_nb, float3 minimum, float3 maximum,
+    Solution<Pt, Solver>& points, unsigned int n_0 = 0, unsigned seed = 0)
+{
+    const auto scale = dist_to_nb / 0.8;
+    random_cuboid(0.8, minimum / scale, maximum / scale, points, n_0, seed);
+    const int n = *points.h_n;
+    const int steps = n <= 3000 ? 1000 : (n <= 12000 ? 2000 : 3000);
+    ya::relax_and_rescale(scale, points, steps, 15000);
+}

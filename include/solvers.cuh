@@ -1,0 +1,637 @@
+// Solvers for N-body problems of spheroid cells on MI355X (gfx950).
+//
+// Source-level API parity with ya||a `include/solvers.cuh` (reference lines
+// cited per item): Pairwise_interaction / Pairwise_friction / Generic_forces
+// signatures and the default frictions (:15-50), Solution<Pt, Solver> (:56-106),
+// Heun_solver with set_fixed* (:164-276), Tile_solver (:279-342), Grid with its
+// four public arrays and d_grid mirror (:380-425), __constant__ d_nhood[27]
+// (:428), Grid_solver with public cube_size (:465-502).
+//
+// The implementation is new and CDNA4-first; what differs from the reference:
+//
+//  * One fused force kernel per stage.  The reference runs 3 fills, the force
+//    kernel, add_rhs, a thrust::reduce with a blocking device->host copy and the
+//    update kernel (:231-255).  Here the force kernel writes
+//    dX = gen + F + sum_v / sum_friction directly (no fills, no add_rhs, no
+//    d_sum_v / d_sum_friction arrays), the centre-of-mass mean is reduced on the
+//    device into a buffer the update kernel reads, and nothing but the 4-byte
+//    read of n at step entry (:229) touches the host.
+//  * Grid force: cells are processed in cube-sorted order from a gathered,
+//    16-byte-aligned copy {X, id} (+ old_v) so neighbour reads are contiguous:
+//    the 27 stencil cubes are 9 x-rows of 3 consecutive cube ids, i.e. 9
+//    contiguous slot ranges of the sorted array; they are walked in exactly the
+//    reference's d_nhood order (:472-483) and ascending point id inside a cube,
+//    so every per-cell sum is accumulated in the reference's order.
+//  * Tile force: 64-thread (one wavefront) workgroups, 256-point LDS tiles
+//    holding X and old_v, two barriers per tile (the reference's single barrier
+//    at :302 is only safe for a 32-thread block on a 32-wide warp).
+//  * One thread owns one cell i for the whole stage, as in the reference:
+//    functors may update per-i state non-atomically
+//    (examples/passive_growth.cu:48-51) and see original point ids.
+//
+// Arithmetic contract: pair distance is sqrtf(fmaf(z,z,fmaf(y,y,x*x))); all
+// other arithmetic is the reference's statement-by-statement binary32.  Build
+// model files with -ffp-contract=off to reproduce the CPU oracle bit for bit.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <assert.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <functional>
+#include <vector>
+
+#include "cudebug.cuh"
+#include "dtypes.cuh"
+#include "yalla_hip.h"
+
+
+// Interactions are specified between two points Xi and Xj with r = Xi - Xj
+// (solvers.cuh:15-19).
+template<typename Pt>
+using Pairwise_interaction = Pt(Pt Xi, Pt r, float dist, int i, int j);
+
+// Pairwise friction coefficient (solvers.cuh:21-41).
+template<typename Pt>
+using Pairwise_friction = float(Pt Xi, Pt r, float dist, int i, int j);
+
+template<typename Pt>
+__device__ float friction_w_neighbour(Pt Xi, Pt r, float dist, int i, int j)
+{
+    if (i == j) return 0;
+    return dist < 1 ? 1 : 0;
+}
+
+template<typename Pt>
+__device__ float friction_on_background(Pt Xi, Pt r, float dist, int i, int j)
+{
+    return 0;
+}
+
+// Optional generic forces, run before the pairwise interactions
+// (solvers.cuh:43-53).
+template<typename Pt>
+using Generic_forces =
+    std::function<void(const int n, const Pt* __restrict__ d_X, Pt* d_dX)>;
+
+template<typename Pt>
+void no_gen_forces(const int n, const Pt* __restrict__ d_X, Pt* d_dX)
+{}
+
+
+namespace ya {
+
+constexpr int FORCE_BLOCK = 256;   // grid force: 4 wavefronts per workgroup
+constexpr int TILE_BLOCK = 64;     // tile force: one wavefront per workgroup
+constexpr int TILE_POINTS = 256;   // points staged in LDS per tile
+constexpr int UPDATE_BLOCK = 256;
+
+// One cell in cube-sorted order: the point and its original id.  16-byte
+// entries (float3) load as one dwordx4.
+template<typename Pt>
+struct alignas((sizeof(Pt) + 4) % 16 == 0 ? 16 : ((sizeof(Pt) + 4) % 8 == 0 ? 8 : 4)) Entry {
+    Pt X;
+    int id;
+};
+
+__device__ __forceinline__ float dist3(float x, float y, float z)
+{
+    return sqrtf(fmaf(z, z, fmaf(y, y, x * x)));
+}
+
+// Optional HIP-event timing of the force-kernel launches (bench.py's roofline
+// leg).  Disabled by default; when disabled mark() is a no-op.
+class Profiler {
+public:
+    void enable(bool on) { enabled = on; }
+    void mark()
+    {
+        if (!enabled) return;
+        if (used == events.size()) {
+            hipEvent_t e;
+            YA_CHECK((int)hipEventCreate(&e));
+            events.push_back(e);
+        }
+        YA_CHECK((int)hipEventRecord(events[used++], nullptr));
+    }
+    // Sum of (after - before) over the recorded launches; resets the record.
+    void read(double* total_ms, int* launches)
+    {
+        YA_CHECK((int)hipDeviceSynchronize());
+        double ms = 0;
+        for (size_t k = 0; k + 1 < used; k += 2) {
+            float span = 0;
+            YA_CHECK((int)hipEventElapsedTime(&span, events[k], events[k + 1]));
+            ms += span;
+        }
+        if (total_ms) *total_ms = ms;
+        if (launches) *launches = (int)(used / 2);
+        used = 0;
+    }
+    ~Profiler()
+    {
+        for (auto e : events) (void)hipEventDestroy(e);
+    }
+
+private:
+    bool enabled = false;
+    size_t used = 0;
+    std::vector<hipEvent_t> events;
+};
+
+template<typename Pt>
+bool is_no_gen_forces(const Generic_forces<Pt>& f)
+{
+    using Fn = void (*)(const int, const Pt* __restrict__, Pt*);
+    auto* target = f.template target<Fn>();
+    return target && *target == static_cast<Fn>(&no_gen_forces<Pt>);
+}
+
+// dX = gen + F, then the friction term of add_rhs (solvers.cuh:146-161).
+template<typename Pt>
+__device__ __forceinline__ void store_rhs(
+    Pt* __restrict__ d_dX, int i, bool has_gen, Pt F, float3 sum_v, float sum_friction)
+{
+    Pt dX;
+    if (has_gen) {
+        dX = d_dX[i];
+        dX += F;
+    } else {
+        dX = F;
+    }
+    if (sum_friction > 0) {
+        dX.x += sum_v.x / sum_friction;
+        dX.y += sum_v.y / sum_friction;
+        dX.z += sum_v.z / sum_friction;
+    }
+    d_dX[i] = dX;
+}
+
+// All-pairs force (replaces compute_tile, solvers.cuh:284-322): j ascending,
+// functor called for every (i, j) including i == j.
+template<typename Pt, Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction>
+__global__ __launch_bounds__(TILE_BLOCK) void tile_force(const int n,
+    const Pt* __restrict__ d_X, const float3* __restrict__ d_old_v, Pt* __restrict__ d_dX,
+    const bool has_gen)
+{
+    __shared__ Pt sh_X[TILE_POINTS];
+    __shared__ float3 sh_v[TILE_POINTS];
+
+    const int i = blockIdx.x * TILE_BLOCK + threadIdx.x;
+    Pt Xi = ya::zero<Pt>();
+    if (i < n) Xi = d_X[i];
+    Pt F = ya::zero<Pt>();
+    float3 sum_v{0.f, 0.f, 0.f};
+    float sum_friction = 0;
+    for (int tile_start = 0; tile_start < n; tile_start += TILE_POINTS) {
+        const int n_tile = min(TILE_POINTS, n - tile_start);
+        __syncthreads();
+        for (int k = threadIdx.x; k < n_tile; k += TILE_BLOCK) {
+            sh_X[k] = d_X[tile_start + k];
+            sh_v[k] = d_old_v[tile_start + k];
+        }
+        __syncthreads();
+        if (i < n) {
+            for (int k = 0; k < n_tile; k++) {
+                const int j = tile_start + k;
+                Pt r = Xi - sh_X[k];
+                float dist = dist3(r.x, r.y, r.z);
+                F += pw_int(Xi, r, dist, i, j);
+                float friction = pw_friction(Xi, r, dist, i, j);
+                sum_friction += friction;
+                if (friction != 0) {
+                    float3 v = sh_v[k];
+                    sum_v.x += friction * v.x;
+                    sum_v.y += friction * v.y;
+                    sum_v.z += friction * v.z;
+                }
+            }
+        }
+    }
+    if (i < n) store_rhs(d_dX, i, has_gen, F, sum_v, sum_friction);
+}
+
+// Row r of the 27-cube stencil in the reference's d_nhood order
+// (solvers.cuh:472-483): rows of three consecutive cube ids centred on
+// 0, -gs, +gs, then the same three shifted by -gs^2, then by +gs^2.
+__device__ __forceinline__ int stencil_row_offset(int row, int gs)
+{
+    const int dy = row % 3, dz = row / 3;
+    const int oy = dy == 0 ? 0 : (dy == 1 ? -gs : gs);
+    const int oz = dz == 0 ? 0 : (dz == 1 ? -gs * gs : gs * gs);
+    return oy + oz;
+}
+
+// Grid force (replaces compute_cube, solvers.cuh:430-463).  Thread s owns
+// sorted slot s.  offs[c] = first slot of cube c, so the cubes c-1, c, c+1 of a
+// stencil row are the contiguous slots [offs[c-1], offs[c+2]).
+template<typename Pt, Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction>
+__global__ __launch_bounds__(FORCE_BLOCK) void grid_force(const int n,
+    const Entry<Pt>* __restrict__ sorted, const float4* __restrict__ sorted_v,
+    const int* __restrict__ cube_id, const int* __restrict__ offs, const int gs,
+    const int n_cubes, const float cube_size, Pt* __restrict__ d_dX, const bool has_gen)
+{
+    const int s = blockIdx.x * FORCE_BLOCK + threadIdx.x;
+    if (s >= n) return;
+
+    const Entry<Pt> self = sorted[s];
+    const Pt Xi = self.X;
+    const int i = self.id;
+    const int c = cube_id[s];
+    Pt F = ya::zero<Pt>();
+    float3 sum_v{0.f, 0.f, 0.f};
+    float sum_friction = 0;
+    for (int row = 0; row < 9; row++) {
+        const int mid = c + stencil_row_offset(row, gs);
+        // The reference indexes cube_start/end without bounds checks
+        // (solvers.cuh:444); out-of-grid cubes are treated as empty here.
+        const int first = min(max(mid - 1, 0), n_cubes);
+        const int last = min(max(mid + 2, 0), n_cubes);
+        const int k_end = offs[last];
+        for (int k = offs[first]; k < k_end; k++) {
+            const Entry<Pt> other = sorted[k];
+            Pt r = Xi - other.X;
+            float dist = dist3(r.x, r.y, r.z);
+            if (dist >= cube_size) continue;
+
+            const int j = other.id;
+            F += pw_int(Xi, r, dist, i, j);
+            float friction = pw_friction(Xi, r, dist, i, j);
+            sum_friction += friction;
+            if (friction != 0) {
+                float4 v = sorted_v[k];
+                sum_v.x += friction * v.x;
+                sum_v.y += friction * v.y;
+                sum_v.z += friction * v.z;
+            }
+        }
+    }
+    store_rhs(d_dX, i, has_gen, F, sum_v, sum_friction);
+}
+
+// fix = what is subtracted from dX.xyz: 0 = mean (already in d_mean), 1 = the
+// fixed point's value, 2 = the point's x, y and the mean's z (set_fixed_xy,
+// solvers.cuh:243-249).
+template<typename Pt>
+__global__ void make_fix(int mode, const float* __restrict__ d_mean,
+    const Pt* __restrict__ d_point, float* __restrict__ d_fix)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (mode == 1) {
+        d_fix[0] = d_point->x;
+        d_fix[1] = d_point->y;
+        d_fix[2] = d_point->z;
+    } else {
+        d_fix[0] = d_point->x;
+        d_fix[1] = d_point->y;
+        d_fix[2] = d_mean[2];
+    }
+}
+
+}  // namespace ya
+
+
+// 2nd order solver for the equation v = F + <v(t - dt)> for x, y, and z, where
+// <v> is the mean velocity of the neighbours weighted by the friction
+// coefficients; other variables in Pt follow dw/dt = F_w (solvers.cuh:109-144).
+// The fixed velocity is read from device memory instead of a kernel argument.
+template<typename Pt>
+__global__ __launch_bounds__(ya::UPDATE_BLOCK) void euler_step(const int n, const float dt,
+    const Pt* __restrict__ d_X0, const float* __restrict__ d_fix, Pt* __restrict__ d_dX,
+    Pt* __restrict__ d_X)
+{
+    const int i = blockIdx.x * ya::UPDATE_BLOCK + threadIdx.x;
+    if (i >= n) return;
+
+    Pt dX = d_dX[i];
+    dX.x -= d_fix[0];
+    dX.y -= d_fix[1];
+    dX.z -= d_fix[2];
+    d_dX[i] = dX;
+    d_X[i] = d_X0[i] + dX * dt;
+}
+
+template<typename Pt>
+__global__ __launch_bounds__(ya::UPDATE_BLOCK) void heun_step(const int n, const float dt,
+    const Pt* __restrict__ d_dX, const float* __restrict__ d_fix1, Pt* __restrict__ d_dX1,
+    Pt* __restrict__ d_X, float3* __restrict__ d_old_v)
+{
+    const int i = blockIdx.x * ya::UPDATE_BLOCK + threadIdx.x;
+    if (i >= n) return;
+
+    Pt dX1 = d_dX1[i];
+    dX1.x -= d_fix1[0];
+    dX1.y -= d_fix1[1];
+    dX1.z -= d_fix1[2];
+    d_dX1[i] = dX1;
+    const Pt dX = d_dX[i];
+    Pt X = d_X[i];
+    X += (dX + dX1) * 0.5 * dt;
+    d_X[i] = X;
+    d_old_v[i] = float3{
+        (dX.x + dX1.x) * 0.5f, (dX.y + dX1.y) * 0.5f, (dX.z + dX1.z) * 0.5f};
+}
+
+
+// Solution<Pt, Solver> combines a method, Solver, with a point type, Pt: host
+// mirror of the variables plus access to the device arrays (solvers.cuh:56-106).
+template<typename Pt, template<typename> class Solver>
+class Solution : public Solver<Pt> {
+public:
+    Pt* h_X;                                      // Current variables on host
+    Pt* const d_X = Solver<Pt>::d_X;              // Variables on device (GPU)
+    float3* const d_old_v = Solver<Pt>::d_old_v;  // Velocities from previous step
+    int* const h_n = (int*)malloc(sizeof(int));   // Number of points
+    int* const d_n = Solver<Pt>::d_n;
+    const int n_max;
+    template<typename... Args>
+    Solution(int n_max, Args... args) : Solver<Pt>{n_max, args...}, n_max{n_max}
+    {
+        *h_n = n_max;
+        h_X = (Pt*)calloc(n_max, sizeof(Pt));
+    }
+    ~Solution()
+    {
+        free(h_X);
+        free(h_n);
+    }
+    Solution(const Solution&) = delete;
+    void copy_to_device()
+    {
+        assert(*h_n <= n_max);
+        YA_CHECK(ya_memcpy_h2d(d_X, h_X, (size_t)n_max * sizeof(Pt)));
+        YA_CHECK(ya_memcpy_h2d(d_n, h_n, sizeof(int)));
+    }
+    void copy_to_host()
+    {
+        YA_CHECK(ya_memcpy_d2h(h_X, d_X, (size_t)n_max * sizeof(Pt)));
+        YA_CHECK(ya_memcpy_d2h(h_n, d_n, sizeof(int)));
+        assert(*h_n <= n_max);
+        Solver<Pt>::check_status();
+    }
+    int get_d_n() { return Solver<Pt>::get_d_n(); }
+    template<Pairwise_interaction<Pt> pw_int>
+    void take_step(float dt, Generic_forces<Pt> gen_forces = no_gen_forces<Pt>)
+    {
+        return Solver<Pt>::template take_step<pw_int, friction_w_neighbour<Pt>>(
+            dt, gen_forces);
+    }
+    template<Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction>
+    void take_step(float dt, Generic_forces<Pt> gen_forces = no_gen_forces<Pt>)
+    {
+        return Solver<Pt>::template take_step<pw_int, pw_friction>(dt, gen_forces);
+    }
+};
+
+
+// Two-stage Heun integrator (solvers.cuh:164-276).  Computer specifies how
+// pairwise interactions are computed.
+template<typename Pt, template<typename> class Computer>
+class Heun_solver : public Computer<Pt> {
+public:
+    template<typename... Args>
+    Heun_solver(int n_max, Args... args) : Computer<Pt>{n_max, args...}, n_max{n_max}
+    {
+        const size_t pts = (size_t)n_max * sizeof(Pt);
+        YA_CHECK(ya_malloc((void**)&d_X, pts));
+        YA_CHECK(ya_malloc((void**)&d_dX, pts));
+        YA_CHECK(ya_malloc((void**)&d_X1, pts));
+        YA_CHECK(ya_malloc((void**)&d_dX1, pts));
+        YA_CHECK(ya_malloc((void**)&d_old_v, (size_t)n_max * sizeof(float3)));
+        YA_CHECK(ya_memset_async(d_old_v, 0, (size_t)n_max * sizeof(float3), nullptr));
+        YA_CHECK(ya_malloc((void**)&d_n, sizeof(int)));
+        YA_CHECK(ya_malloc((void**)&d_mean, 2 * sizeof(Pt)));
+        YA_CHECK(ya_malloc((void**)&d_fix, 4 * sizeof(float)));
+        YA_CHECK(ya_malloc((void**)&d_workspace, ya_reduce_workspace_bytes(n_floats)));
+    }
+    ~Heun_solver()
+    {
+        ya_free(d_X);
+        ya_free(d_dX);
+        ya_free(d_X1);
+        ya_free(d_dX1);
+        ya_free(d_old_v);
+        ya_free(d_n);
+        ya_free(d_mean);
+        ya_free(d_fix);
+        ya_free(d_workspace);
+    }
+    Heun_solver(const Heun_solver&) = delete;
+    void set_fixed() { fix_com = true; }
+    void set_fixed(int point_id)
+    {
+        fix_com = false;
+        fix_point = point_id;
+    }
+    void set_fixed_xy(int point_id)
+    {
+        fix_com = false;
+        fix_com_z = true;
+        fix_point = point_id;
+    }
+
+protected:
+    static constexpr int n_floats = ya::N_floats<Pt>::value;
+    Pt *d_X, *d_dX, *d_X1, *d_dX1;
+    float3* d_old_v;
+    int* d_n;
+    float *d_mean, *d_fix, *d_workspace;
+    bool fix_com = true;
+    bool fix_com_z = false;
+    int fix_point = 0;
+    const int n_max;
+    int get_d_n()
+    {
+        int n;
+        YA_CHECK(ya_get_n(d_n, &n));
+        assert(n <= n_max);
+        return n;
+    }
+    void check_status() { Computer<Pt>::check_status(); }
+
+    // The velocity subtracted from dX.xyz for this stage, left in device memory.
+    const float* fix_velocity(int n, Pt* d_rhs, bool mean, bool point_xy)
+    {
+        if (mean) {  // solvers.cuh:241-249 / :266-268
+            YA_CHECK(ya_reduce_mean(d_rhs, n_floats, n, d_mean, d_workspace, nullptr));
+            if (!point_xy) return d_mean;
+            ya::make_fix<Pt><<<1, 1>>>(2, d_mean, d_rhs + fix_point, d_fix);
+            return d_fix;
+        }
+        ya::make_fix<Pt><<<1, 1>>>(1, d_mean, d_rhs + fix_point, d_fix);  // :250-253
+        return d_fix;
+    }
+
+    template<Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction>
+    void take_step(float dt, Generic_forces<Pt> gen_forces)
+    {
+        const int n = get_d_n();
+        if (n <= 0) return;
+        const bool has_gen = !ya::is_no_gen_forces<Pt>(gen_forces);
+        const int blocks = (n + ya::UPDATE_BLOCK - 1) / ya::UPDATE_BLOCK;
+
+        // 1st stage
+        if (has_gen) {
+            YA_CHECK(ya_memset_async(d_dX, 0, (size_t)n * sizeof(Pt), nullptr));
+            gen_forces(n, d_X, d_dX);
+        }
+        Computer<Pt>::template pwints<pw_int, pw_friction>(n, d_X, d_old_v, d_dX, has_gen);
+        const float* fix_dX = fix_velocity(n, d_dX, fix_com or fix_com_z, fix_com_z);
+        euler_step<<<blocks, ya::UPDATE_BLOCK>>>(n, dt, d_X, fix_dX, d_dX, d_X1);
+
+        // 2nd stage
+        if (has_gen) {
+            YA_CHECK(ya_memset_async(d_dX1, 0, (size_t)n * sizeof(Pt), nullptr));
+            gen_forces(n, d_X1, d_dX1);
+        }
+        Computer<Pt>::template pwints<pw_int, pw_friction>(n, d_X1, d_old_v, d_dX1, has_gen);
+        const float* fix_dX1 = fix_velocity(n, d_dX1, fix_com, false);
+        heun_step<<<blocks, ya::UPDATE_BLOCK>>>(n, dt, d_dX, fix_dX1, d_dX1, d_X, d_old_v);
+    }
+};
+
+
+// All-pairs interactions, LDS-tiled (solvers.cuh:279-342).  TILE_SIZE is kept
+// for source compatibility; the kernel's own tile is ya::TILE_POINTS.
+const auto TILE_SIZE = 32;
+
+template<typename Pt>
+class Tile_computer {
+public:
+    Tile_computer(int n_max) {}
+    ya::Profiler profiler;
+
+protected:
+    void check_status() {}
+    template<Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction>
+    void pwints(const int n, const Pt* __restrict__ d_X, const float3* __restrict__ d_old_v,
+        Pt* d_dX, const bool has_gen)
+    {
+        profiler.mark();
+        ya::tile_force<Pt, pw_int, pw_friction>
+            <<<(n + ya::TILE_BLOCK - 1) / ya::TILE_BLOCK, ya::TILE_BLOCK>>>(
+                n, d_X, d_old_v, d_dX, has_gen);
+        profiler.mark();
+    }
+};
+
+template<typename Pt>
+using Tile_solver = Heun_solver<Pt, Tile_computer>;
+
+
+// Uniform grid over space: cells sorted by cube id, ONLY points closer than
+// cube_size interact (solvers.cuh:345-425).  The four arrays and the device
+// mirror d_grid are public API used from model kernels, e.g.
+// `d_grid->d_cube_start[cube]`.
+class Grid {
+public:
+    int *d_cube_id, *d_point_id, *d_cube_start, *d_cube_end;
+    Grid* d_grid;
+    const int n_max, grid_size, n_cubes;
+    Grid(int n_max, int gs = 50) : n_max{n_max}, grid_size{gs}, n_cubes{gs * gs * gs}
+    {
+        YA_CHECK(ya_grid_create(n_max, gs, &handle));
+        YA_CHECK(ya_grid_arrays(handle, &d_cube_id, &d_point_id, &d_cube_start, &d_cube_end));
+        YA_CHECK(ya_grid_offsets(handle, &d_offs));
+        YA_CHECK(ya_malloc((void**)&d_grid, sizeof(Grid)));
+        YA_CHECK(ya_memcpy_h2d(d_grid, this, sizeof(Grid)));
+    }
+    ~Grid()
+    {
+        ya_free(d_grid);
+        ya_grid_destroy(handle);
+    }
+    Grid(const Grid&) = delete;
+    template<typename Pt>
+    void build(const int n, const Pt* __restrict__ d_X, const float cube_size = 1)
+    {
+        YA_CHECK(ya_grid_build(handle, d_X, sizeof(Pt), n, cube_size, nullptr));
+    }
+    template<typename Pt, template<typename> class Solver>
+    void build(Solution<Pt, Solver>& points, const float cube_size = 1)
+    {
+        auto n = points.get_d_n();
+        assert(n <= n_max);
+        build(n, points.d_X, cube_size);
+    }
+    // Engine-side extras (not in the reference).
+    template<typename Pt>
+    void build_sorted(const int n, const Pt* d_X, const float3* d_old_v, const float cube_size,
+        ya::Entry<Pt>* d_sorted, float4* d_sorted_v)
+    {
+        YA_CHECK(ya_grid_build_sorted(handle, d_X, sizeof(Pt), d_old_v, n, cube_size, d_sorted,
+            sizeof(ya::Entry<Pt>), d_sorted_v, nullptr));
+    }
+    const int* offsets() const { return d_offs; }
+    void check_status()
+    {
+        int bits = 0;
+        YA_CHECK(ya_grid_status(handle, &bits, 1));
+        if (bits & YA_STATUS_OUT_OF_GRID) {
+            fprintf(stderr,
+                "yalla-hip: a cell left the %d^3 grid (device assertion at "
+                "ya||a solvers.cuh:361-362); enlarge grid_size or cube_size.\n",
+                grid_size);
+            abort();
+        }
+    }
+
+private:
+    ya_grid* handle = nullptr;
+    const int* d_offs = nullptr;
+};
+
+
+__constant__ int d_nhood[27];  // stencil offsets for model kernels (solvers.cuh:428)
+
+template<typename Pt>
+class Grid_computer {
+public:
+    float cube_size;
+    ya::Profiler profiler;
+    Grid_computer(int n_max, int grid_size = 50, float cube_size = 1)
+        : cube_size{cube_size}, grid{n_max, grid_size}
+    {
+        // Row-major 3x3x3 offsets in the order x, then {0,-gs,+gs}, then
+        // {0,-gs^2,+gs^2} (solvers.cuh:472-483).
+        int h_nhood[27];
+        const int shift[3] = {0, -1, 1};
+        for (int z = 0; z < 3; z++)
+            for (int y = 0; y < 3; y++)
+                for (int x = 0; x < 3; x++)
+                    h_nhood[9 * z + 3 * y + x] =
+                        (x - 1) + shift[y] * grid_size + shift[z] * grid_size * grid_size;
+        YA_CHECK((int)hipMemcpyToSymbol(HIP_SYMBOL(d_nhood), h_nhood, sizeof(h_nhood)));
+        YA_CHECK(ya_malloc((void**)&d_sorted, (size_t)n_max * sizeof(ya::Entry<Pt>)));
+        YA_CHECK(ya_malloc((void**)&d_sorted_v, (size_t)n_max * sizeof(float4)));
+    }
+    ~Grid_computer()
+    {
+        ya_free(d_sorted);
+        ya_free(d_sorted_v);
+    }
+    Grid_computer(const Grid_computer&) = delete;
+
+protected:
+    Grid grid;
+    ya::Entry<Pt>* d_sorted;
+    float4* d_sorted_v;
+    void check_status() { grid.check_status(); }
+    template<Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction>
+    void pwints(const int n, const Pt* __restrict__ d_X, const float3* __restrict__ d_old_v,
+        Pt* d_dX, const bool has_gen)
+    {
+        grid.build_sorted(n, d_X, d_old_v, cube_size, d_sorted, d_sorted_v);
+        profiler.mark();
+        ya::grid_force<Pt, pw_int, pw_friction>
+            <<<(n + ya::FORCE_BLOCK - 1) / ya::FORCE_BLOCK, ya::FORCE_BLOCK>>>(n, d_sorted,
+                d_sorted_v, grid.d_cube_id, grid.offsets(), grid.grid_size, grid.n_cubes,
+                cube_size, d_dX, has_gen);
+        profiler.mark();
+    }
+};
+
+template<typename Pt>
+using Grid_solver = Heun_solver<Pt, Grid_computer>;

@@ -1,0 +1,114 @@
+/* yalla_hip.h -- C ABI of libyalla_hip.so, the Pt-agnostic half of the
+ * MI355X-native ya||a step path.
+ *
+ * The reference (germannp/yalla) is a header-only CUDA template library and
+ * has no FFI; its boundary for the hot path is the header API
+ * `Solution<Pt, Solver>::take_step<pw_int, pw_friction>(dt, gen_forces)`
+ * (include/solvers.cuh:60-106).  This repo keeps that header API
+ * (include/solvers.cuh, links.cuh, dtypes.cuh ...) and puts every piece that
+ * does not depend on the point type or on the user's functor behind the plain
+ * C entry points below: plain pointers and sizes, no C++ or HIP types, every
+ * function returns a hipError_t value as int (0 = success).  Each entry point
+ * cites the reference interface it replaces.  `stream` is a hipStream_t passed
+ * as void* (NULL = the default stream, which is what the reference uses
+ * throughout).
+ *
+ * The functor-carrying kernels (tile force, grid force, link forces) and the
+ * Pt-typed Heun updates are templates in the headers and are instantiated in
+ * the model's translation unit by hipcc, exactly where the reference
+ * instantiates compute_tile / compute_cube / link.
+ */
+#ifndef YALLA_HIP_H
+#define YALLA_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YA_ABI_VERSION 1
+
+/* Status bits reported by ya_grid_status(). */
+#define YA_STATUS_OUT_OF_GRID 1 /* a cell's cube id fell outside [0, n_cubes):
+                                   the reference's D_ASSERT at
+                                   solvers.cuh:361-362 */
+
+int ya_abi_version(void);
+
+/* Device memory owned by the solver classes.  Replaces the cudaMalloc /
+ * cudaFree pairs of Heun_solver (solvers.cuh:171-195), Grid (:387-403),
+ * Links (links.cuh:36-52) and Property (property.cuh:17-25). */
+int ya_malloc(void** d_ptr, size_t bytes);
+int ya_free(void* d_ptr);
+int ya_memset_async(void* d_ptr, int value, size_t bytes, void* stream);
+int ya_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes);
+int ya_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes);
+int ya_memcpy_d2d_async(void* d_dst, const void* d_src, size_t bytes, void* stream);
+int ya_device_synchronize(void);
+
+/* Blocking read of the device-side point count.  Replaces
+ * Heun_solver::get_d_n (solvers.cuh:219-225) and Links::get_d_n
+ * (links.cuh:58-64); the caller asserts n <= n_max as the reference does. */
+int ya_get_n(const int* d_n, int* n_out);
+
+/* ---- Uniform grid (spatial hash) -------------------------------------- */
+
+typedef struct ya_grid ya_grid;
+
+/* Replaces Grid::Grid (solvers.cuh:384-395): allocates the four public
+ * arrays d_cube_id[n_max], d_point_id[n_max], d_cube_start[n_cubes],
+ * d_cube_end[n_cubes] (n_cubes = grid_size^3) plus private scratch. */
+int ya_grid_create(int n_max, int grid_size, ya_grid** out);
+int ya_grid_destroy(ya_grid* g);
+
+/* Device pointers of the four public arrays (stable for the grid's life). */
+int ya_grid_arrays(ya_grid* g, int** d_cube_id, int** d_point_id,
+    int** d_cube_start, int** d_cube_end);
+
+/* Device pointer to the private exclusive prefix offs[0 .. n_cubes]:
+ * offs[c] = number of cells in cubes < c, offs[n_cubes] = n.  Sorted slots of
+ * cube c are [offs[c], offs[c + 1]). */
+int ya_grid_offsets(ya_grid* g, const int** d_offs);
+
+/* Replaces Grid::build(n, d_X, cube_size) (solvers.cuh:406-417), i.e.
+ * compute_cube_id (:349-365) + 2x thrust::fill + thrust::sort_by_key +
+ * compute_cube_start_and_end (:367-378).  d_X is an array of n points of
+ * `stride_bytes` each whose first three floats are x, y, z.  Results are
+ * bit-identical to the reference's: the cube id is evaluated in binary32 in
+ * the reference's association order, cells are ordered by (cube id, point id)
+ * (= stable sort by cube id), empty cubes get start -1 / end -2. */
+int ya_grid_build(ya_grid* g, const void* d_X, size_t stride_bytes, int n,
+    float cube_size, void* stream);
+
+/* ya_grid_build + a gather of the cells into sorted order for the force
+ * kernel: d_sorted_X[slot] = { point (stride_bytes), int point_id, padding up
+ * to entry_bytes }, d_sorted_v[slot] = { old_v.x, old_v.y, old_v.z, 0 } (16 B).
+ * d_old_v is the float3 array of solvers.cuh:66 (12-byte elements). */
+int ya_grid_build_sorted(ya_grid* g, const void* d_X, size_t stride_bytes,
+    const void* d_old_v, int n, float cube_size, void* d_sorted_X,
+    size_t entry_bytes, void* d_sorted_v, void* stream);
+
+/* Sticky status bits (YA_STATUS_*); blocking 4-byte read.  `clear` != 0
+ * resets them. */
+int ya_grid_status(ya_grid* g, int* bits, int clear);
+
+/* ---- Centre-of-mass reduction ---------------------------------------- */
+
+/* Replaces `thrust::reduce(d_dX, d_dX + n, Pt{0}) / n` (solvers.cuh:242,268)
+ * without the device->host round trip.  d_v holds n points of n_floats packed
+ * floats.  Writes to device memory d_out[0 .. n_floats) the mean (sum *
+ * float(1.0 / n), the reference's operator/ arithmetic, dtypes.cuh:202-217)
+ * and to d_out[n_floats .. 2 n_floats) the plain sum.  The summation order is
+ * fixed (DESIGN.md "deterministic COM reduction"), so results are
+ * reproducible run to run.  d_workspace must hold 1024 * n_floats floats. */
+int ya_reduce_mean(const void* d_v, int n_floats, int n, float* d_out,
+    float* d_workspace, void* stream);
+
+/* Size in bytes of the workspace ya_reduce_mean needs. */
+size_t ya_reduce_workspace_bytes(int n_floats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YALLA_HIP_H */

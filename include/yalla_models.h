@@ -1,0 +1,97 @@
+/* yalla_models.h -- C ABI of the model harness.
+ *
+ * ya||a models are C++ translation units that instantiate
+ * Solution<Pt, Solver>::take_step<functor>() (reference examples/ directory).  To
+ * drive that template API from Python (tests/, bench.py) without a compiler in
+ * the loop, libyalla_models.so instantiates it for a fixed table of named
+ * models -- the BASELINE.json configurations and the reference's own test
+ * cases -- and exposes each through the handle-based entry points below.
+ *
+ * The same header is implemented twice from the same model source
+ * (yalla_amd/csrc/model_functors.h + models_harness.inc):
+ *   - yalla_amd/libyalla_models.so : hipcc, the .cuh headers -> HIP kernels on
+ *     the GPU (the product path);
+ *   - oracle/_build/liboracle_models.so : g++, oracle/yalla_host.hpp -> the
+ *     serial CPU restatement (test infrastructure only).
+ * so a parity test makes the identical sequence of calls on both.
+ *
+ * All functions return 0 on success, a negative value for a harness error
+ * (unknown model, unsupported call for this model), or abort the process on a
+ * HIP error (the engine fails loudly; there is no fallback).
+ */
+#ifndef YALLA_MODELS_H
+#define YALLA_MODELS_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ya_sim ya_sim;
+
+/* 1 = HIP engine, 0 = CPU oracle. */
+int ya_models_is_device(void);
+/* Number of models and their names ("springs_grid", "clipped_tile", ...). */
+int ya_models_count(void);
+const char* ya_models_name(int index);
+
+/* Construct Solution<Pt, Solver>{n_max[, grid_size, cube_size]} for the named
+ * model (solvers.cuh:60-74; grid args are ignored by Tile_solver models). */
+int ya_sim_create(const char* model, int n_max, int grid_size, float cube_size, ya_sim** out);
+void ya_sim_destroy(ya_sim* sim);
+
+int ya_sim_n_floats(ya_sim* sim); /* floats per point: 3, 4, 5, 7 ... */
+int ya_sim_n_max(ya_sim* sim);
+float* ya_sim_h_X(ya_sim* sim);   /* host mirror h_X, n_max * n_floats floats */
+int ya_sim_set_h_n(ya_sim* sim, int n);
+int ya_sim_get_h_n(ya_sim* sim);
+int ya_sim_copy_to_device(ya_sim* sim); /* solvers.cuh:80-85 */
+int ya_sim_copy_to_host(ya_sim* sim);   /* solvers.cuh:86-91 */
+int ya_sim_get_d_n(ya_sim* sim);        /* solvers.cuh:92 */
+
+/* n_steps calls of take_step<pw_int, pw_friction>(dt, gen_forces) followed by
+ * the model's post-step kernel if it has one (e.g. proliferation). */
+int ya_sim_take_steps(ya_sim* sim, float dt, int n_steps);
+/* Block until the device is idle (no-op on the oracle). */
+int ya_sim_synchronize(ya_sim* sim);
+
+/* mode 0 = set_fixed(), 1 = set_fixed(point), 2 = set_fixed_xy(point)
+ * (solvers.cuh:196-208). */
+int ya_sim_set_fixed(ya_sim* sim, int mode, int point);
+int ya_sim_set_cube_size(ya_sim* sim, float cube_size); /* public member, :468 */
+
+/* inits.cuh:33-51 with an explicit seed; fills h_X[n_0 .. h_n) and copies to
+ * the device. */
+int ya_sim_random_sphere(ya_sim* sim, float dist_to_nb, unsigned seed);
+
+/* Copies of device-side state for checks: d_old_v (3 floats per point, n_max
+ * points) and, for Grid_solver models, the four public Grid arrays as left by
+ * the last build (sizes n_max, n_max, grid_size^3, grid_size^3). */
+int ya_sim_get_old_v(ya_sim* sim, float* out);
+int ya_sim_get_grid(ya_sim* sim, int* cube_id, int* point_id, int* cube_start, int* cube_end);
+/* Run Grid::build(points, cube_size) on a fresh public Grid{n_max, grid_size}
+ * (tests/test_solvers.cu:247-315) and return its arrays. */
+int ya_sim_build_grid(ya_sim* sim, int grid_size, float cube_size, int* cube_id, int* point_id,
+    int* cube_start, int* cube_end);
+
+/* Model parameters (e.g. "n_cells" for the sorting model). */
+int ya_sim_set_param(ya_sim* sim, const char* name, double value);
+/* Integer per-cell properties of a model ("type", "mes_nbs", "epi_nbs"). */
+int ya_sim_set_prop(ya_sim* sim, const char* name, const int* values, int n);
+int ya_sim_get_prop(ya_sim* sim, const char* name, int* values, int n);
+/* Links of a model that has them: n_links pairs (a, b), then copy_to_device. */
+int ya_sim_set_links(ya_sim* sim, const int* ab, int n_links, float strength);
+
+/* Oracle only: 0 = serial COM sum, 1 = the engine's documented tree order.
+ * Returns -1 on the device build. */
+int ya_sim_set_reduce_order(ya_sim* sim, int order);
+
+/* Device only: accumulate HIP-event timings of the dominant kernel's launches
+ * (the force kernel) while enabled; read back as total milliseconds and launch
+ * count.  Returns -1 on the oracle. */
+int ya_sim_profile(ya_sim* sim, int enable);
+int ya_sim_profile_read(ya_sim* sim, double* total_ms, int* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YALLA_MODELS_H */

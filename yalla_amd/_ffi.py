@@ -1,0 +1,84 @@
+"""ctypes binding of the model-harness C ABI (include/yalla_models.h).
+
+`bind(path)` loads any shared library that implements that header and declares
+the argument types of every entry point.  `device_lib()` loads the HIP build,
+yalla_amd/libyalla_models.so (which pulls in libyalla_hip.so through its
+$ORIGIN rpath) and raises if it is missing: the product has no CPU fallback.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEVICE_LIB = os.path.join(_HERE, "libyalla_models.so")
+CORE_LIB = os.path.join(_HERE, "libyalla_hip.so")
+
+_pf = C.POINTER(C.c_float)
+_pi = C.POINTER(C.c_int)
+_sim = C.c_void_p
+
+# name -> (restype, argtypes); mirrors include/yalla_models.h one to one.
+MODELS_ABI = {
+    "ya_models_is_device": (C.c_int, []),
+    "ya_models_count": (C.c_int, []),
+    "ya_models_name": (C.c_char_p, [C.c_int]),
+    "ya_sim_create": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_float, C.POINTER(_sim)]),
+    "ya_sim_destroy": (None, [_sim]),
+    "ya_sim_n_floats": (C.c_int, [_sim]),
+    "ya_sim_n_max": (C.c_int, [_sim]),
+    "ya_sim_h_X": (_pf, [_sim]),
+    "ya_sim_set_h_n": (C.c_int, [_sim, C.c_int]),
+    "ya_sim_get_h_n": (C.c_int, [_sim]),
+    "ya_sim_copy_to_device": (C.c_int, [_sim]),
+    "ya_sim_copy_to_host": (C.c_int, [_sim]),
+    "ya_sim_get_d_n": (C.c_int, [_sim]),
+    "ya_sim_take_steps": (C.c_int, [_sim, C.c_float, C.c_int]),
+    "ya_sim_synchronize": (C.c_int, [_sim]),
+    "ya_sim_set_fixed": (C.c_int, [_sim, C.c_int, C.c_int]),
+    "ya_sim_set_cube_size": (C.c_int, [_sim, C.c_float]),
+    "ya_sim_random_sphere": (C.c_int, [_sim, C.c_float, C.c_uint]),
+    "ya_sim_get_old_v": (C.c_int, [_sim, _pf]),
+    "ya_sim_get_grid": (C.c_int, [_sim, _pi, _pi, _pi, _pi]),
+    "ya_sim_build_grid": (C.c_int, [_sim, C.c_int, C.c_float, _pi, _pi, _pi, _pi]),
+    "ya_sim_set_param": (C.c_int, [_sim, C.c_char_p, C.c_double]),
+    "ya_sim_set_prop": (C.c_int, [_sim, C.c_char_p, _pi, C.c_int]),
+    "ya_sim_get_prop": (C.c_int, [_sim, C.c_char_p, _pi, C.c_int]),
+    "ya_sim_set_links": (C.c_int, [_sim, _pi, C.c_int, C.c_float]),
+    "ya_sim_set_reduce_order": (C.c_int, [_sim, C.c_int]),
+    "ya_sim_profile": (C.c_int, [_sim, C.c_int]),
+    "ya_sim_profile_read": (C.c_int, [_sim, C.POINTER(C.c_double), _pi]),
+}
+
+# include/yalla_hip.h, for the export check (no compute calls without a GPU).
+CORE_ABI = [
+    "ya_abi_version", "ya_malloc", "ya_free", "ya_memset_async", "ya_memcpy_h2d",
+    "ya_memcpy_d2h", "ya_memcpy_d2d_async", "ya_device_synchronize", "ya_get_n",
+    "ya_grid_create", "ya_grid_destroy", "ya_grid_arrays", "ya_grid_offsets",
+    "ya_grid_build", "ya_grid_build_sorted", "ya_grid_status", "ya_reduce_mean",
+    "ya_reduce_workspace_bytes",
+]
+
+
+def bind(path):
+    """Load `path` and type every include/yalla_models.h entry point."""
+    if not os.path.exists(path):
+        raise FileNotFoundError(
+            f"{path} is missing: build it first (python -c 'import __graft_entry__ as g; g.build()')")
+    lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in MODELS_ABI.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+_device = None
+
+
+def device_lib():
+    """The HIP engine.  Raises if the extension has not been built."""
+    global _device
+    if _device is None:
+        _device = bind(DEVICE_LIB)
+        if _device.ya_models_is_device() != 1:
+            raise RuntimeError(f"{DEVICE_LIB} is not the HIP build")
+    return _device

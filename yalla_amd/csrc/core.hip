@@ -1,0 +1,474 @@
+// libyalla_hip.so -- Pt-agnostic kernels of the MI355X ya||a step path behind
+// the C ABI of include/yalla_hip.h.  gfx950 only; wave = 64 lanes.
+//
+// Grid build (replaces solvers.cuh:349-378,406-417).  The reference bins, fills
+// two gs^3 tables, radix-sorts (cube id, point id) pairs and detects segment
+// bounds: >= 6 passes over the keys plus 16 B x gs^3 of fills per build.  Cube
+// ids are small dense integers, so this build is a counting sort instead:
+//
+//   k_bin      cube id per cell (binary32, reference association order) and
+//              an arrival rank from one returning atomic on count[cube]
+//   k_tile_sum per-tile totals of count[] (tile = 2048 cubes)
+//   k_scan     exclusive prefix -> offs[], cube_start[], cube_end[] for EVERY
+//              cube (so no fills are needed), and count[] re-zeroed in passing
+//   k_scatter  slot = offs[cube] + rank (arrival order inside a cube)
+//   k_order    restores ascending point id inside each cube (what a stable
+//              sort yields) by rank-counting within the cube's segment, and
+//              optionally gathers {X, id} and old_v into sorted order so the
+//              force kernel streams them.
+//
+// Everything is int32/fp32; compile with -ffp-contract=off so the cube id
+// arithmetic is the plain IEEE evaluation the oracle restates.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "yalla_hip.h"
+
+namespace {
+
+constexpr int BLOCK = 256;
+constexpr int SCAN_ITEMS = 8;                   // cubes per thread in the scan
+constexpr int SCAN_TILE = BLOCK * SCAN_ITEMS;   // cubes per block
+constexpr int REDUCE_MAX_BLOCKS = 1024;
+
+inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+// --- binning ---------------------------------------------------------------
+// solvers.cuh:357-360 evaluated in float, left to right:
+//   (floor(x/cs) + gs/2) + (floor(y/cs) + gs/2)*gs + (floor(z/cs) + gs/2)*gs*gs
+__device__ __forceinline__ int cube_id_of(float x, float y, float z, float cs, int gs)
+{
+    const float half = (float)(gs / 2);
+    const float fgs = (float)gs;
+    float fx = floorf(x / cs) + half;
+    float fy = (floorf(y / cs) + half) * fgs;
+    float fz = ((floorf(z / cs) + half) * fgs) * fgs;
+    return (int)((fx + fy) + fz);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_bin(const float* __restrict__ X,
+    int stride_f, int n, float cs, int gs, int n_cubes, int* __restrict__ cube_of,
+    int* __restrict__ rank, int* __restrict__ count, int* __restrict__ status)
+{
+    int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const float* p = X + (size_t)i * stride_f;
+    int id = cube_id_of(p[0], p[1], p[2], cs, gs);
+    if (id < 0 || id >= n_cubes) {
+        atomicOr(status, YA_STATUS_OUT_OF_GRID);
+        id = id < 0 ? 0 : n_cubes - 1;
+    }
+    cube_of[i] = id;
+    rank[i] = atomicAdd(&count[id], 1);
+}
+
+// --- scan over cubes ---------------------------------------------------------
+__device__ __forceinline__ int block_sum(int v, int* sh)
+{
+    // wave reduce, then 4 waves through LDS
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__global__ __launch_bounds__(BLOCK) void k_tile_sum(
+    const int* __restrict__ count, int* __restrict__ tile_sums)
+{
+    __shared__ int sh[4];
+    const int4* c4 = reinterpret_cast<const int4*>(count + (size_t)blockIdx.x * SCAN_TILE);
+    int4 a = c4[threadIdx.x * 2], b = c4[threadIdx.x * 2 + 1];
+    int v = a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
+    int s = block_sum(v, sh);
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_scan(int* __restrict__ count,
+    const int* __restrict__ tile_sums, int n_cubes, int n, int* __restrict__ offs,
+    int* __restrict__ cube_start, int* __restrict__ cube_end)
+{
+    __shared__ int sh[4];
+    __shared__ int sh_wave[4];
+    // cells in all tiles before this one
+    int before = 0;
+    for (int t = threadIdx.x; t < (int)blockIdx.x; t += BLOCK) before += tile_sums[t];
+    before = block_sum(before, sh);
+
+    size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
+    int4* c4 = reinterpret_cast<int4*>(count + base);
+    int4 a = c4[0], b = c4[1];
+    int c[SCAN_ITEMS] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    int total = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) total += c[k];
+    // exclusive scan of the 256 thread totals: inclusive wave scan + wave offsets
+    int incl = total;
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int o = 1; o < 64; o <<= 1) {
+        int up = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += up;
+    }
+    if (lane == 63) sh_wave[w] = incl;
+    __syncthreads();
+    int wave_off = 0;
+    for (int k = 0; k < w; k++) wave_off += sh_wave[k];
+    int run = before + wave_off + incl - total;
+
+    int o_[SCAN_ITEMS], s_[SCAN_ITEMS], e_[SCAN_ITEMS];
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        o_[k] = run;
+        s_[k] = c[k] > 0 ? run : -1;             // solvers.cuh:411 sentinel
+        e_[k] = c[k] > 0 ? run + c[k] - 1 : -2;  // solvers.cuh:412 sentinel
+        run += c[k];
+    }
+    int4* o4 = reinterpret_cast<int4*>(offs + base);
+    int4* s4 = reinterpret_cast<int4*>(cube_start + base);
+    int4* e4 = reinterpret_cast<int4*>(cube_end + base);
+    o4[0] = make_int4(o_[0], o_[1], o_[2], o_[3]);
+    o4[1] = make_int4(o_[4], o_[5], o_[6], o_[7]);
+    s4[0] = make_int4(s_[0], s_[1], s_[2], s_[3]);
+    s4[1] = make_int4(s_[4], s_[5], s_[6], s_[7]);
+    e4[0] = make_int4(e_[0], e_[1], e_[2], e_[3]);
+    e4[1] = make_int4(e_[4], e_[5], e_[6], e_[7]);
+    c4[0] = make_int4(0, 0, 0, 0);  // leave count[] zeroed for the next build
+    c4[1] = make_int4(0, 0, 0, 0);
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == BLOCK - 1)
+        offs[(size_t)gridDim.x * SCAN_TILE] = n;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_scatter(const int* __restrict__ cube_of,
+    const int* __restrict__ rank, const int* __restrict__ offs, int n,
+    int* __restrict__ arrival_pid, int* __restrict__ cube_id_sorted)
+{
+    int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    int c = cube_of[i];
+    int s = offs[c] + rank[i];
+    arrival_pid[s] = i;
+    cube_id_sorted[s] = c;
+}
+
+// Rank-count inside the cube's segment: slot of point p = segment start +
+// #(points of the segment with a smaller id).  NW = floats per point (0 = no
+// gather).
+template<int NW>
+__global__ __launch_bounds__(BLOCK) void k_order(const int* __restrict__ arrival_pid,
+    const int* __restrict__ cube_id_sorted, const int* __restrict__ offs, int n,
+    int* __restrict__ point_id, const float* __restrict__ X, int stride_f,
+    const float* __restrict__ old_v, float* __restrict__ sorted_X, int entry_f,
+    float4* __restrict__ sorted_v)
+{
+    int s = blockIdx.x * BLOCK + threadIdx.x;
+    if (s >= n) return;
+    int c = cube_id_sorted[s];
+    int a = offs[c], b = offs[c + 1];
+    int p = arrival_pid[s];
+    int smaller = 0;
+    for (int t = a; t < b; t++) smaller += arrival_pid[t] < p;
+    int dst = a + smaller;
+    point_id[dst] = p;
+    if (NW > 0) {
+        const float* src = X + (size_t)p * stride_f;
+        float* out = sorted_X + (size_t)dst * entry_f;
+        float v[NW > 0 ? NW : 1];
+#pragma unroll
+        for (int k = 0; k < NW; k++) v[k] = src[k];
+#pragma unroll
+        for (int k = 0; k < NW; k++) out[k] = v[k];
+        out[NW] = __int_as_float(p);
+        const float* ov = old_v + (size_t)p * 3;
+        sorted_v[dst] = make_float4(ov[0], ov[1], ov[2], 0.f);
+    }
+}
+
+// --- deterministic reduction -----------------------------------------------
+// B = clamp(ceil(n/256), 1, 1024) blocks; lane (b, t) sums i = b*256 + t,
+// += B*256 ... serially; block folds 256 lanes by halving through LDS; then one
+// block sums the B partials the same way.  The oracle restates this order
+// (oracle/yalla_host.hpp, YA_REDUCE_TREE).
+template<int NW>
+__device__ __forceinline__ void fold256(float (&acc)[NW], float* sh /* [NW][256] */)
+{
+#pragma unroll
+    for (int k = 0; k < NW; k++) sh[k * BLOCK + threadIdx.x] = acc[k];
+    __syncthreads();
+    for (int s = BLOCK / 2; s >= 1; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+#pragma unroll
+            for (int k = 0; k < NW; k++)
+                sh[k * BLOCK + threadIdx.x] =
+                    sh[k * BLOCK + threadIdx.x] + sh[k * BLOCK + threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+}
+
+template<int NW>
+__global__ __launch_bounds__(BLOCK) void k_reduce_partial(
+    const float* __restrict__ v, int n, float* __restrict__ partials)
+{
+    __shared__ float sh[NW * BLOCK];
+    float acc[NW];
+#pragma unroll
+    for (int k = 0; k < NW; k++) acc[k] = 0.f;
+    for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * BLOCK) {
+        const float* p = v + (size_t)i * NW;
+#pragma unroll
+        for (int k = 0; k < NW; k++) acc[k] = acc[k] + p[k];
+    }
+    fold256<NW>(acc, sh);
+    if (threadIdx.x < NW) partials[(size_t)blockIdx.x * NW + threadIdx.x] = sh[threadIdx.x * BLOCK];
+}
+
+template<int NW>
+__global__ __launch_bounds__(BLOCK) void k_reduce_final(
+    const float* __restrict__ partials, int n_partials, int n, float* __restrict__ out)
+{
+    __shared__ float sh[NW * BLOCK];
+    float acc[NW];
+#pragma unroll
+    for (int k = 0; k < NW; k++) acc[k] = 0.f;
+    for (int p = threadIdx.x; p < n_partials; p += BLOCK) {
+#pragma unroll
+        for (int k = 0; k < NW; k++) acc[k] = acc[k] + partials[(size_t)p * NW + k];
+    }
+    fold256<NW>(acc, sh);
+    if (threadIdx.x < NW) {
+        float sum = sh[threadIdx.x * BLOCK];
+        // Pt / n  ==  Pt * float(1. / float(n))   (dtypes.cuh:202-217)
+        float inv = (float)(1. / (double)(float)n);
+        out[threadIdx.x] = sum * inv;
+        out[NW + threadIdx.x] = sum;
+    }
+}
+
+template<int NW>
+int launch_reduce(const float* v, int n, float* out, float* ws, hipStream_t st)
+{
+    int B = ceil_div(n, BLOCK);
+    if (B < 1) B = 1;
+    if (B > REDUCE_MAX_BLOCKS) B = REDUCE_MAX_BLOCKS;
+    k_reduce_partial<NW><<<B, BLOCK, 0, st>>>(v, n, ws);
+    k_reduce_final<NW><<<1, BLOCK, 0, st>>>(ws, B, n, out);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+struct ya_grid {
+    int n_max, grid_size, n_cubes, n_tiles;
+    size_t padded;  // n_cubes rounded up to whole scan tiles
+    int *d_cube_id, *d_point_id, *d_cube_start, *d_cube_end;  // public
+    int *d_offs, *d_count, *d_tile_sums;                      // private
+    int *d_cube_of, *d_rank, *d_arrival;                      // private, [n_max]
+    int* d_status;
+};
+
+#define YA_TRY(expr)                      \
+    do {                                  \
+        hipError_t e_ = (expr);           \
+        if (e_ != hipSuccess) return (int)e_; \
+    } while (0)
+
+extern "C" {
+
+int ya_abi_version(void) { return YA_ABI_VERSION; }
+
+int ya_malloc(void** p, size_t bytes) { return (int)hipMalloc(p, bytes ? bytes : 4); }
+int ya_free(void* p) { return (int)hipFree(p); }
+int ya_memset_async(void* p, int value, size_t bytes, void* stream)
+{
+    if (bytes == 0) return 0;
+    return (int)hipMemsetAsync(p, value, bytes, (hipStream_t)stream);
+}
+int ya_memcpy_h2d(void* d, const void* h, size_t bytes)
+{
+    return (int)hipMemcpy(d, h, bytes, hipMemcpyHostToDevice);
+}
+int ya_memcpy_d2h(void* h, const void* d, size_t bytes)
+{
+    return (int)hipMemcpy(h, d, bytes, hipMemcpyDeviceToHost);
+}
+int ya_memcpy_d2d_async(void* dst, const void* src, size_t bytes, void* stream)
+{
+    return (int)hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+}
+int ya_device_synchronize(void) { return (int)hipDeviceSynchronize(); }
+
+int ya_get_n(const int* d_n, int* n_out)
+{
+    return (int)hipMemcpy(n_out, d_n, sizeof(int), hipMemcpyDeviceToHost);
+}
+
+int ya_grid_create(int n_max, int grid_size, ya_grid** out)
+{
+    if (!out || n_max < 0 || grid_size < 1 || grid_size > 1290) return (int)hipErrorInvalidValue;
+    ya_grid* g = (ya_grid*)calloc(1, sizeof(ya_grid));
+    if (!g) return (int)hipErrorOutOfMemory;
+    g->n_max = n_max;
+    g->grid_size = grid_size;
+    g->n_cubes = grid_size * grid_size * grid_size;
+    g->n_tiles = ceil_div(g->n_cubes, SCAN_TILE);
+    g->padded = (size_t)g->n_tiles * SCAN_TILE;
+    size_t nb = (size_t)(n_max > 0 ? n_max : 1) * sizeof(int);
+    size_t cb = (g->padded + 4) * sizeof(int);
+    YA_TRY(hipMalloc(&g->d_cube_id, nb));
+    YA_TRY(hipMalloc(&g->d_point_id, nb));
+    YA_TRY(hipMalloc(&g->d_cube_of, nb));
+    YA_TRY(hipMalloc(&g->d_rank, nb));
+    YA_TRY(hipMalloc(&g->d_arrival, nb));
+    YA_TRY(hipMalloc(&g->d_cube_start, cb));
+    YA_TRY(hipMalloc(&g->d_cube_end, cb));
+    YA_TRY(hipMalloc(&g->d_offs, cb));
+    YA_TRY(hipMalloc(&g->d_count, cb));
+    YA_TRY(hipMalloc(&g->d_tile_sums, (size_t)g->n_tiles * sizeof(int)));
+    YA_TRY(hipMalloc(&g->d_status, sizeof(int)));
+    YA_TRY(hipMemset(g->d_count, 0, cb));
+    YA_TRY(hipMemset(g->d_offs, 0, cb));
+    YA_TRY(hipMemset(g->d_cube_start, 0xff, cb));
+    YA_TRY(hipMemset(g->d_cube_end, 0xff, cb));
+    YA_TRY(hipMemset(g->d_status, 0, sizeof(int)));
+    *out = g;
+    return 0;
+}
+
+int ya_grid_destroy(ya_grid* g)
+{
+    if (!g) return 0;
+    (void)hipFree(g->d_cube_id);
+    (void)hipFree(g->d_point_id);
+    (void)hipFree(g->d_cube_of);
+    (void)hipFree(g->d_rank);
+    (void)hipFree(g->d_arrival);
+    (void)hipFree(g->d_cube_start);
+    (void)hipFree(g->d_cube_end);
+    (void)hipFree(g->d_offs);
+    (void)hipFree(g->d_count);
+    (void)hipFree(g->d_tile_sums);
+    (void)hipFree(g->d_status);
+    free(g);
+    return 0;
+}
+
+int ya_grid_arrays(ya_grid* g, int** cube_id, int** point_id, int** cube_start, int** cube_end)
+{
+    if (!g) return (int)hipErrorInvalidValue;
+    if (cube_id) *cube_id = g->d_cube_id;
+    if (point_id) *point_id = g->d_point_id;
+    if (cube_start) *cube_start = g->d_cube_start;
+    if (cube_end) *cube_end = g->d_cube_end;
+    return 0;
+}
+
+int ya_grid_offsets(ya_grid* g, const int** d_offs)
+{
+    if (!g || !d_offs) return (int)hipErrorInvalidValue;
+    *d_offs = g->d_offs;
+    return 0;
+}
+
+int ya_grid_build_sorted(ya_grid* g, const void* d_X, size_t stride_bytes,
+    const void* d_old_v, int n, float cube_size, void* d_sorted_X, size_t entry_bytes,
+    void* d_sorted_v, void* stream)
+{
+    if (!g || n < 0 || n > g->n_max || stride_bytes < 12 || stride_bytes % 4)
+        return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    const int stride_f = (int)(stride_bytes / 4);
+    const int nb = ceil_div(n, BLOCK);
+    if (n > 0)
+        k_bin<<<nb, BLOCK, 0, st>>>((const float*)d_X, stride_f, n, cube_size, g->grid_size,
+            g->n_cubes, g->d_cube_of, g->d_rank, g->d_count, g->d_status);
+    k_tile_sum<<<g->n_tiles, BLOCK, 0, st>>>(g->d_count, g->d_tile_sums);
+    k_scan<<<g->n_tiles, BLOCK, 0, st>>>(g->d_count, g->d_tile_sums, g->n_cubes, n, g->d_offs,
+        g->d_cube_start, g->d_cube_end);
+    if (n > 0) {
+        k_scatter<<<nb, BLOCK, 0, st>>>(
+            g->d_cube_of, g->d_rank, g->d_offs, n, g->d_arrival, g->d_cube_id);
+        const bool gather = d_sorted_X != nullptr;
+        if (gather && (entry_bytes < stride_bytes + 4 || entry_bytes % 4 || !d_sorted_v || !d_old_v))
+            return (int)hipErrorInvalidValue;
+        const int entry_f = (int)(entry_bytes / 4);
+#define YA_ORDER(NW)                                                                     \
+    case NW:                                                                             \
+        k_order<NW><<<nb, BLOCK, 0, st>>>(g->d_arrival, g->d_cube_id, g->d_offs, n,      \
+            g->d_point_id, (const float*)d_X, stride_f, (const float*)d_old_v,           \
+            (float*)d_sorted_X, entry_f, (float4*)d_sorted_v);                           \
+        break;
+        switch (gather ? stride_f : 0) {
+            YA_ORDER(0)
+            YA_ORDER(3)
+            YA_ORDER(4)
+            YA_ORDER(5)
+            YA_ORDER(6)
+            YA_ORDER(7)
+            YA_ORDER(8)
+            YA_ORDER(9)
+            YA_ORDER(10)
+            YA_ORDER(11)
+            YA_ORDER(12)
+            YA_ORDER(13)
+            YA_ORDER(14)
+            YA_ORDER(15)
+            YA_ORDER(16)
+            default:
+                return (int)hipErrorInvalidValue;  // points of > 16 floats: not built
+        }
+#undef YA_ORDER
+    }
+    return (int)hipGetLastError();
+}
+
+int ya_grid_build(ya_grid* g, const void* d_X, size_t stride_bytes, int n, float cube_size,
+    void* stream)
+{
+    return ya_grid_build_sorted(
+        g, d_X, stride_bytes, nullptr, n, cube_size, nullptr, 0, nullptr, stream);
+}
+
+int ya_grid_status(ya_grid* g, int* bits, int clear)
+{
+    if (!g || !bits) return (int)hipErrorInvalidValue;
+    YA_TRY(hipMemcpy(bits, g->d_status, sizeof(int), hipMemcpyDeviceToHost));
+    if (clear && *bits) YA_TRY(hipMemset(g->d_status, 0, sizeof(int)));
+    return 0;
+}
+
+size_t ya_reduce_workspace_bytes(int n_floats)
+{
+    return (size_t)REDUCE_MAX_BLOCKS * (size_t)n_floats * sizeof(float);
+}
+
+int ya_reduce_mean(const void* d_v, int n_floats, int n, float* d_out, float* d_ws, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    const float* v = (const float*)d_v;
+    switch (n_floats) {
+#define YA_RED(NW) \
+    case NW:       \
+        return launch_reduce<NW>(v, n, d_out, d_ws, st);
+        YA_RED(3)
+        YA_RED(4)
+        YA_RED(5)
+        YA_RED(6)
+        YA_RED(7)
+        YA_RED(8)
+        YA_RED(9)
+        YA_RED(10)
+        YA_RED(11)
+        YA_RED(12)
+        YA_RED(13)
+        YA_RED(14)
+        YA_RED(15)
+        YA_RED(16)
+#undef YA_RED
+        default:
+            return (int)hipErrorInvalidValue;
+    }
+}
+
+}  // extern "C"
