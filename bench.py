@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py -- cell-updates/s of Solution<float3, Grid_solver>::take_step<spring>
+on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one take_step (two force evaluations + two grid builds + the Heun
+update) over every cell of a random_sphere(0.5, seed 42) system with the
+`spring` functor of examples/springs.cu clipped by the grid cut-off
+(cube_size 1), friction_w_neighbour, dt = 0.001.  One cell-update = one cell
+advanced by one take_step.  N = 1 runs the 1 M-cell configuration the metric is
+quoted on.  Inputs are resident in HBM before the timed region; nothing inside
+it touches the host except take_step's own 4-byte read of n.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+# Algorithmic bytes, float3 points: P = 12, V = 12, I = 4.
+FORCE_BYTES_PER_CELL = 12 + 12 + 2 * 4 + 12   # force kernel: r P + V + 2I, w P
+STEP_BYTES_PER_CELL = 13 * 12 + 108           # whole take_step: 13 P + 3 V + 18 I = 264
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--cells", type=int, default=1_000_000, help="cells per GPU")
+    ap.add_argument("--grid-size", type=int, default=0, help="0 = smallest that fits")
+    ap.add_argument("--dist", type=float, default=0.5, help="random_sphere spacing")
+    ap.add_argument("--cpu-steps", type=int, default=2, help="oracle steps for cpu_baseline")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-variant", type=int, default=1,
+                    help="1 = LDS-staged grid_force (default), 0 = grid_force_direct (A/B)")
+    return ap.parse_args()
+
+
+def grid_size_for(n, dist):
+    """Smallest even grid that keeps a random_sphere(dist) of n cells, radius
+    (n/0.64)^(1/3) dist/2, two cubes inside the border (cube_size 1)."""
+    radius = (n / 0.64) ** (1.0 / 3) * dist / 2
+    gs = 2 * (int(radius) + 3)
+    return max(gs, 8)
+
+
+def cpu_baseline(n, gs, dist, steps):
+    """The oracle (oracle/, a plain C++ port of the reference's algorithm, one
+    thread) timed on the same workload: `steps` take_steps of the same system."""
+    from yalla_amd import _ffi
+    from yalla_amd.solution import Solution
+
+    path = os.path.join(ROOT, "oracle", "_build", "liboracle_models.so")
+    lib = _ffi.bind(path)
+    with Solution("springs_grid", n, gs, 1.0, lib=lib) as s:
+        s.random_sphere(dist, 42)
+        t0 = time.perf_counter()
+        s.take_step(0.001, steps)
+        dt = time.perf_counter() - t0
+    return {
+        "value": n * steps / dt,
+        "unit": "cell-updates/s",
+        "cores": 1,
+        "host_cores": os.cpu_count(),
+        "kind": "port",
+        "sample": f"{steps} take_steps of the same {n}-cell system (oracle/yalla_host.hpp, g++ -O3, 1 thread)",
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (the HIP engine has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from yalla_amd.solution import Solution
+
+    n = args.cells
+    gs = args.grid_size or grid_size_for(n, args.dist)
+    sim = Solution("springs_grid", n, gs, 1.0)
+    # Independent systems per rank (different seeds): Grid_solver partitions by
+    # independent cell sets; see DESIGN.md "Multi-GPU".
+    sim.random_sphere(args.dist, 42 + rank)
+    sim.set_param("force_variant", args.force_variant)
+    dt = 0.001
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    sim.take_step(dt, args.warmup)
+    barrier()
+    sim.profile(True)
+    t0 = time.perf_counter()
+    sim.take_step(dt, args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    force_ms, launches = sim.profile_read()
+    sim.profile(False)
+    assert sim.get_d_n() == n
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        total_cells = n * world
+        value = total_cells * args.steps / elapsed
+        force_s = force_ms / 1e3 / max(launches, 1)
+        achieved = n * FORCE_BYTES_PER_CELL / force_s / 1e9
+        out = {
+            "metric": "cell-updates/sec at 1M cells (Grid_solver)",
+            "value": value,
+            "unit": "cell-updates/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic: random_sphere(%g) seed 42+rank, glibc rand()" % args.dist,
+            "config": {
+                "workload": "Solution<float3, Grid_solver>::take_step<spring> (examples/springs.cu "
+                            "functor, friction_w_neighbour), dt 0.001",
+                "cells_per_gpu": n,
+                "total_cells": total_cells,
+                "grid_size": gs,
+                "cube_size": 1.0,
+                "parallelism": "1 GPU" if world == 1 else f"{world} independent systems",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "ya::grid_force<float3, spring, friction_w_neighbour>",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "bytes_per_launch": n * FORCE_BYTES_PER_CELL,
+                "avg_launch_us": force_s * 1e6,
+                "launches": launches,
+                "whole_step_achieved_GBs": STEP_BYTES_PER_CELL * value / world / 1e9,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(n, gs, args.dist, args.cpu_steps)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -37,6 +37,7 @@
 #include <hip/hip_runtime.h>
 
 #include <assert.h>
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -227,8 +228,11 @@ __device__ __forceinline__ int stencil_row_offset(int row, int gs)
 // Grid force (replaces compute_cube, solvers.cuh:430-463).  Thread s owns
 // sorted slot s.  offs[c] = first slot of cube c, so the cubes c-1, c, c+1 of a
 // stencil row are the contiguous slots [offs[c-1], offs[c+2]).
+//
+// grid_force_direct is the plain form (neighbours read straight from the
+// sorted array through L1/L2); it is kept as the A/B baseline for grid_force.
 template<typename Pt, Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction>
-__global__ __launch_bounds__(FORCE_BLOCK) void grid_force(const int n,
+__global__ __launch_bounds__(FORCE_BLOCK) void grid_force_direct(const int n,
     const Entry<Pt>* __restrict__ sorted, const float4* __restrict__ sorted_v,
     const int* __restrict__ cube_id, const int* __restrict__ offs, const int gs,
     const int n_cubes, const float cube_size, Pt* __restrict__ d_dX, const bool has_gen)
@@ -269,6 +273,108 @@ __global__ __launch_bounds__(FORCE_BLOCK) void grid_force(const int n,
         }
     }
     store_rhs(d_dX, i, has_gen, F, sum_v, sum_friction);
+}
+
+// Smallest binary32 t with sqrtf(t) >= cube_size.  sqrtf is monotonic and
+// correctly rounded on host and device, so `d2 < t` is exactly the reference's
+// `dist < cube_size` (solvers.cuh:450) without a square root per candidate.
+inline float cutoff_squared(float cube_size)
+{
+    float t = cube_size * cube_size;
+    while (t > 0 && sqrtf(t) >= cube_size) t = nextafterf(t, 0.f);
+    while (sqrtf(t) < cube_size) t = nextafterf(t, INFINITY);
+    return t;
+}
+
+constexpr int STAGE_CELLS = 512;  // sorted cells staged in LDS at a time
+
+// LDS-staged grid force.  A workgroup owns 256 consecutive sorted slots, i.e. a
+// run of cubes [c_lo, c_hi] along x.  For stencil row r every neighbour of every
+// cell of the workgroup lies in the contiguous slots
+// [offs[c_lo + off_r - 1], offs[c_hi + off_r + 2]), so the workgroup streams that
+// range through LDS in chunks (coalesced 16-byte loads) and each thread walks its
+// own sub-range [offs[c + off_r - 1], offs[c + off_r + 2]) out of LDS, rows in
+// the reference's d_nhood order and slots ascending: per-cell sums are
+// accumulated in the reference's order.
+//
+// Each thread handles its candidates 32 at a time in two phases so that the
+// expensive part runs with most lanes busy: phase 1 only tests d2 < cut2 and
+// records a 32-bit hit mask (~15 % of the 27-cube volume is inside the cut-off
+// sphere); phase 2 walks the set bits and evaluates distance, functor, friction
+// and the old_v term.
+template<typename Pt, Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction>
+__global__ __launch_bounds__(FORCE_BLOCK) void grid_force(const int n,
+    const Entry<Pt>* __restrict__ sorted, const float4* __restrict__ sorted_v,
+    const int* __restrict__ cube_id, const int* __restrict__ offs, const int gs,
+    const int n_cubes, const float cut2, Pt* __restrict__ d_dX, const bool has_gen)
+{
+    __shared__ Entry<Pt> sh[STAGE_CELLS];
+
+    const int s0 = blockIdx.x * FORCE_BLOCK;
+    const int s = s0 + threadIdx.x;
+    const bool active = s < n;
+    const int c_lo = cube_id[s0];
+    const int c_hi = cube_id[min(s0 + FORCE_BLOCK, n) - 1];
+
+    Pt Xi = ya::zero<Pt>();
+    int i = 0, c = c_lo;
+    if (active) {
+        const Entry<Pt> self = sorted[s];
+        Xi = self.X;
+        i = self.id;
+        c = cube_id[s];
+    }
+    Pt F = ya::zero<Pt>();
+    float3 sum_v{0.f, 0.f, 0.f};
+    float sum_friction = 0;
+
+    for (int row = 0; row < 9; row++) {
+        const int off = stencil_row_offset(row, gs);
+        const int wg_begin = offs[min(max(c_lo + off - 1, 0), n_cubes)];
+        const int wg_end = offs[min(max(c_hi + off + 2, 0), n_cubes)];
+        const int k_begin = offs[min(max(c + off - 1, 0), n_cubes)];
+        const int k_end = active ? offs[min(max(c + off + 2, 0), n_cubes)] : k_begin;
+
+        for (int chunk = wg_begin; chunk < wg_end; chunk += STAGE_CELLS) {
+            const int chunk_n = min(STAGE_CELLS, wg_end - chunk);
+            __syncthreads();
+            for (int t = threadIdx.x; t < chunk_n; t += FORCE_BLOCK) sh[t] = sorted[chunk + t];
+            __syncthreads();
+
+            const int a = max(k_begin, chunk);
+            const int b = min(k_end, chunk + chunk_n);
+            for (int base = a; base < b; base += 32) {
+                const Entry<Pt>* cand = sh + (base - chunk);
+                const int m = min(32, b - base);
+                unsigned hits = 0;
+                for (int t = 0; t < m; t++) {
+                    const float dx = Xi.x - cand[t].X.x;
+                    const float dy = Xi.y - cand[t].X.y;
+                    const float dz = Xi.z - cand[t].X.z;
+                    const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                    hits |= (d2 < cut2 ? 1u : 0u) << t;
+                }
+                while (hits) {
+                    const int t = __builtin_ctz(hits);
+                    hits &= hits - 1;
+                    const Entry<Pt> other = cand[t];
+                    Pt r = Xi - other.X;
+                    float dist = dist3(r.x, r.y, r.z);
+                    const int j = other.id;
+                    F += pw_int(Xi, r, dist, i, j);
+                    float friction = pw_friction(Xi, r, dist, i, j);
+                    sum_friction += friction;
+                    if (friction != 0) {
+                        float4 v = sorted_v[base + t];
+                        sum_v.x += friction * v.x;
+                        sum_v.y += friction * v.y;
+                        sum_v.z += friction * v.z;
+                    }
+                }
+            }
+        }
+    }
+    if (active) store_rhs(d_dX, i, has_gen, F, sum_v, sum_friction);
 }
 
 // fix = what is subtracted from dX.xyz: 0 = mean (already in d_mean), 1 = the
@@ -591,6 +697,7 @@ class Grid_computer {
 public:
     float cube_size;
     ya::Profiler profiler;
+    int force_variant = 1;  // 1 = LDS-staged grid_force, 0 = grid_force_direct (A/B)
     Grid_computer(int n_max, int grid_size = 50, float cube_size = 1)
         : cube_size{cube_size}, grid{n_max, grid_size}
     {
@@ -624,11 +731,16 @@ protected:
         Pt* d_dX, const bool has_gen)
     {
         grid.build_sorted(n, d_X, d_old_v, cube_size, d_sorted, d_sorted_v);
+        const int blocks = (n + ya::FORCE_BLOCK - 1) / ya::FORCE_BLOCK;
         profiler.mark();
-        ya::grid_force<Pt, pw_int, pw_friction>
-            <<<(n + ya::FORCE_BLOCK - 1) / ya::FORCE_BLOCK, ya::FORCE_BLOCK>>>(n, d_sorted,
+        if (force_variant == 0)
+            ya::grid_force_direct<Pt, pw_int, pw_friction><<<blocks, ya::FORCE_BLOCK>>>(n,
+                d_sorted, d_sorted_v, grid.d_cube_id, grid.offsets(), grid.grid_size,
+                grid.n_cubes, cube_size, d_dX, has_gen);
+        else
+            ya::grid_force<Pt, pw_int, pw_friction><<<blocks, ya::FORCE_BLOCK>>>(n, d_sorted,
                 d_sorted_v, grid.d_cube_id, grid.offsets(), grid.grid_size, grid.n_cubes,
-                cube_size, d_dX, has_gen);
+                ya::cutoff_squared(cube_size), d_dX, has_gen);
         profiler.mark();
     }
 };

@@ -26,6 +26,8 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The libraries are built with -fvisibility=hidden; only this C ABI is exported. */
+#pragma GCC visibility push(default)
 
 #define YA_ABI_VERSION 1
 
@@ -108,6 +110,7 @@ int ya_reduce_mean(const void* d_v, int n_floats, int n, float* d_out,
 /* Size in bytes of the workspace ya_reduce_mean needs. */
 size_t ya_reduce_workspace_bytes(int n_floats);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

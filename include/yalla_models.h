@@ -25,6 +25,8 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The libraries are built with -fvisibility=hidden; only this C ABI is exported. */
+#pragma GCC visibility push(default)
 
 typedef struct ya_sim ya_sim;
 
@@ -91,6 +93,7 @@ int ya_sim_set_reduce_order(ya_sim* sim, int order);
 int ya_sim_profile(ya_sim* sim, int enable);
 int ya_sim_profile_read(ya_sim* sim, double* total_ms, int* launches);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

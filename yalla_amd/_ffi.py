@@ -63,7 +63,7 @@ def bind(path):
     if not os.path.exists(path):
         raise FileNotFoundError(
             f"{path} is missing: build it first (python -c 'import __graft_entry__ as g; g.build()')")
-    lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    lib = C.CDLL(path, mode=C.RTLD_LOCAL)
     for name, (res, args) in MODELS_ABI.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
