@@ -69,6 +69,7 @@ int ya_sim_random_sphere(ya_sim* sim, float dist_to_nb, unsigned seed);
  * points) and, for Grid_solver models, the four public Grid arrays as left by
  * the last build (sizes n_max, n_max, grid_size^3, grid_size^3). */
 int ya_sim_get_old_v(ya_sim* sim, float* out);
+int ya_sim_set_old_v(ya_sim* sim, const float* in); /* n_max * 3 floats -> d_old_v */
 int ya_sim_get_grid(ya_sim* sim, int* cube_id, int* point_id, int* cube_start, int* cube_end);
 /* Run Grid::build(points, cube_size) on a fresh public Grid{n_max, grid_size}
  * (tests/test_solvers.cu:247-315) and return its arrays. */

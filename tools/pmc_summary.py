@@ -1,0 +1,17 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 counter_collection CSVs: mean counter value per kernel."""
+import csv, sys, collections, glob
+def main(paths, filt):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for p in paths:
+        for r in csv.DictReader(open(p)):
+            k = r['Kernel_Name']
+            if filt and filt not in k: continue
+            agg[k[:60]][r['Counter_Name']].append(float(r['Counter_Value']))
+    for k, cs in agg.items():
+        print(k)
+        for c, v in sorted(cs.items()):
+            print('   %-28s mean %.4g  (n=%d)' % (c, sum(v)/len(v), len(v)))
+if __name__ == '__main__':
+    filt = sys.argv[2] if len(sys.argv) > 2 else ''
+    main(sorted(glob.glob(sys.argv[1])), filt)

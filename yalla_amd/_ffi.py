@@ -37,6 +37,7 @@ MODELS_ABI = {
     "ya_sim_set_cube_size": (C.c_int, [_sim, C.c_float]),
     "ya_sim_random_sphere": (C.c_int, [_sim, C.c_float, C.c_uint]),
     "ya_sim_get_old_v": (C.c_int, [_sim, _pf]),
+    "ya_sim_set_old_v": (C.c_int, [_sim, _pf]),
     "ya_sim_get_grid": (C.c_int, [_sim, _pi, _pi, _pi, _pi]),
     "ya_sim_build_grid": (C.c_int, [_sim, C.c_int, C.c_float, _pi, _pi, _pi, _pi]),
     "ya_sim_set_param": (C.c_int, [_sim, C.c_char_p, C.c_double]),

@@ -122,6 +122,11 @@ class Solution:
                "get_old_v")
         return out
 
+    def set_old_v(self, v):
+        v = np.ascontiguousarray(v, dtype=np.float32).reshape(self.n_max, 3)
+        _check(self.lib.ya_sim_set_old_v(self._h, v.ctypes.data_as(C.POINTER(C.c_float))),
+               "set_old_v")
+
     def _grid_buffers(self, gs):
         return (np.empty(self.n_max, np.int32), np.empty(self.n_max, np.int32),
                 np.empty(gs ** 3, np.int32), np.empty(gs ** 3, np.int32))
