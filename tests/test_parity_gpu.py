@@ -160,3 +160,26 @@ def test_dynamic_n(oracle, device):
             assert s.get_d_n() == 1234
             out.append(s.positions())
     assert np.array_equal(out[0].view(np.uint32), out[1].view(np.uint32))
+
+
+def test_growing_and_shrinking_n(oracle, device):
+    """Cells appended (n grows) and removed (n shrinks) between steps, as model
+    kernels do through *d_n: the grid's visit order must stay a permutation."""
+    out = []
+    for lib in (oracle, device):
+        with Solution("springs_grid", 4000, 50, 1.0, lib=lib) as s:
+            if lib is oracle:
+                s.set_reduce_order(1)
+            s.random_sphere(0.5, 21)      # all 4000 positions exist on the host
+            snaps = []
+            for n in (1000, 2500, 4000, 700, 3999):
+                s.copy_to_host()
+                s.h_n = n
+                s.copy_to_device()
+                s.take_step(0.001, 2)
+                snaps.append(s.positions())
+                cube_id, point_id, start, end = s.grid()
+                snaps.append(point_id[:n].copy())
+            out.append(snaps)
+    for a, b in zip(*out):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))

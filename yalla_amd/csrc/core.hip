@@ -7,7 +7,11 @@
 // ids are small dense integers, so this build is a counting sort instead:
 //
 //   k_bin      cube id per cell (binary32, reference association order) and
-//              an arrival rank from one returning atomic on count[cube]
+//              an arrival rank from one returning atomic on count[cube].  Cells
+//              are visited in the PREVIOUS build's sorted order (cells move
+//              little between builds), so a wavefront's 64 atomics fall on a
+//              few neighbouring counters instead of 64 random cache lines, and
+//              the later scatter writes neighbouring slots
 //   k_tile_sum per-tile totals of count[] (tile = 2048 cubes)
 //   k_scan     exclusive prefix -> offs[], cube_start[], cube_end[] for EVERY
 //              cube (so no fills are needed), and count[] re-zeroed in passing
@@ -47,20 +51,50 @@ __device__ __forceinline__ int cube_id_of(float x, float y, float z, float cs, i
     return (int)((fx + fy) + fz);
 }
 
-__global__ __launch_bounds__(BLOCK) void k_bin(const float* __restrict__ X,
-    int stride_f, int n, float cs, int gs, int n_cubes, int* __restrict__ cube_of,
-    int* __restrict__ rank, int* __restrict__ count, int* __restrict__ status)
+// Visit order: position s of the previous build's sorted order, identity for
+// cells added since (ids >= n_prev).  A bijection on [0, n) whenever prev_pid is
+// a permutation of [0, n_prev) and n >= n_prev; the host passes n_prev = 0
+// otherwise.
+__device__ __forceinline__ int visit(int s, const int* __restrict__ prev_pid, int n_prev)
 {
-    int i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n) return;
-    const float* p = X + (size_t)i * stride_f;
-    int id = cube_id_of(p[0], p[1], p[2], cs, gs);
-    if (id < 0 || id >= n_cubes) {
-        atomicOr(status, YA_STATUS_OUT_OF_GRID);
-        id = id < 0 ? 0 : n_cubes - 1;
+    return s < n_prev ? prev_pid[s] : s;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_bin(const float* __restrict__ X,
+    int stride_f, int n, float cs, int gs, int n_cubes, const int* __restrict__ prev_pid,
+    int n_prev, int* __restrict__ cube_of, int* __restrict__ rank, int* __restrict__ count,
+    int* __restrict__ status)
+{
+    int s = blockIdx.x * BLOCK + threadIdx.x;
+    int id = -1;
+    if (s < n) {
+        int i = visit(s, prev_pid, n_prev);
+        const float* p = X + (size_t)i * stride_f;
+        id = cube_id_of(p[0], p[1], p[2], cs, gs);
+        if (id < 0 || id >= n_cubes) {
+            atomicOr(status, YA_STATUS_OUT_OF_GRID);
+            id = id < 0 ? 0 : n_cubes - 1;
+        }
     }
-    cube_of[i] = id;
-    rank[i] = atomicAdd(&count[id], 1);
+    // Wave-aggregated counting: in visit order equal cube ids sit in adjacent
+    // lanes, so each run of equal ids issues ONE atomic (by its first lane, for
+    // the run length) instead of one per lane on the same counter.  Any
+    // arrival order inside a cube is fine: k_order restores ascending ids.
+    const int lane = threadIdx.x & 63;
+    const int id_before = __shfl_up(id, 1, 64);
+    const bool head = lane == 0 || id != id_before;
+    const unsigned long long heads = __ballot(head);
+    const unsigned long long upto = heads & (~0ULL >> (63 - lane));          // heads in lanes <= lane
+    const unsigned long long after = lane == 63 ? 0ULL : heads & (~0ULL << (lane + 1));
+    const int head_lane = 63 - __builtin_clzll(upto);
+    const int run_end = after ? __builtin_ctzll(after) : 64;
+    int base = 0;
+    if (head && id >= 0) base = atomicAdd(&count[id], run_end - lane);
+    base = __shfl(base, head_lane, 64);
+    if (s < n) {
+        cube_of[s] = id;
+        rank[s] = base + (lane - head_lane);
+    }
 }
 
 // --- scan over cubes ---------------------------------------------------------
@@ -142,14 +176,15 @@ __global__ __launch_bounds__(BLOCK) void k_scan(int* __restrict__ count,
 
 __global__ __launch_bounds__(BLOCK) void k_scatter(const int* __restrict__ cube_of,
     const int* __restrict__ rank, const int* __restrict__ offs, int n,
-    int* __restrict__ arrival_pid, int* __restrict__ cube_id_sorted)
+    const int* __restrict__ prev_pid, int n_prev, int* __restrict__ arrival_pid,
+    int* __restrict__ cube_id_sorted)
 {
-    int i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n) return;
-    int c = cube_of[i];
-    int s = offs[c] + rank[i];
-    arrival_pid[s] = i;
-    cube_id_sorted[s] = c;
+    int s = blockIdx.x * BLOCK + threadIdx.x;
+    if (s >= n) return;
+    int c = cube_of[s];
+    int slot = offs[c] + rank[s];
+    arrival_pid[slot] = visit(s, prev_pid, n_prev);
+    cube_id_sorted[slot] = c;
 }
 
 // Rank-count inside the cube's segment: slot of point p = segment start +
@@ -158,8 +193,8 @@ __global__ __launch_bounds__(BLOCK) void k_scatter(const int* __restrict__ cube_
 template<int NW>
 __global__ __launch_bounds__(BLOCK) void k_order(const int* __restrict__ arrival_pid,
     const int* __restrict__ cube_id_sorted, const int* __restrict__ offs, int n,
-    int* __restrict__ point_id, const float* __restrict__ X, int stride_f,
-    const float* __restrict__ old_v, float* __restrict__ sorted_X, int entry_f,
+    int* __restrict__ point_id, int* __restrict__ next_prev_pid, const float* __restrict__ X,
+    int stride_f, const float* __restrict__ old_v, float* __restrict__ sorted_X, int entry_f,
     float4* __restrict__ sorted_v)
 {
     int s = blockIdx.x * BLOCK + threadIdx.x;
@@ -171,6 +206,7 @@ __global__ __launch_bounds__(BLOCK) void k_order(const int* __restrict__ arrival
     for (int t = a; t < b; t++) smaller += arrival_pid[t] < p;
     int dst = a + smaller;
     point_id[dst] = p;
+    next_prev_pid[dst] = p;
     if (NW > 0) {
         const float* src = X + (size_t)p * stride_f;
         float* out = sorted_X + (size_t)dst * entry_f;
@@ -265,6 +301,8 @@ struct ya_grid {
     int *d_cube_id, *d_point_id, *d_cube_start, *d_cube_end;  // public
     int *d_offs, *d_count, *d_tile_sums;                      // private
     int *d_cube_of, *d_rank, *d_arrival;                      // private, [n_max]
+    int *d_prev_pid;  // private copy of the last build's point ids (visit order)
+    int n_prev;       // cells in that build; 0 = none / unusable
     int* d_status;
 };
 
@@ -321,6 +359,7 @@ int ya_grid_create(int n_max, int grid_size, ya_grid** out)
     YA_TRY(hipMalloc(&g->d_cube_of, nb));
     YA_TRY(hipMalloc(&g->d_rank, nb));
     YA_TRY(hipMalloc(&g->d_arrival, nb));
+    YA_TRY(hipMalloc(&g->d_prev_pid, nb));
     YA_TRY(hipMalloc(&g->d_cube_start, cb));
     YA_TRY(hipMalloc(&g->d_cube_end, cb));
     YA_TRY(hipMalloc(&g->d_offs, cb));
@@ -344,6 +383,7 @@ int ya_grid_destroy(ya_grid* g)
     (void)hipFree(g->d_cube_of);
     (void)hipFree(g->d_rank);
     (void)hipFree(g->d_arrival);
+    (void)hipFree(g->d_prev_pid);
     (void)hipFree(g->d_cube_start);
     (void)hipFree(g->d_cube_end);
     (void)hipFree(g->d_offs);
@@ -380,15 +420,16 @@ int ya_grid_build_sorted(ya_grid* g, const void* d_X, size_t stride_bytes,
     hipStream_t st = (hipStream_t)stream;
     const int stride_f = (int)(stride_bytes / 4);
     const int nb = ceil_div(n, BLOCK);
+    const int n_prev = n >= g->n_prev ? g->n_prev : 0;
     if (n > 0)
         k_bin<<<nb, BLOCK, 0, st>>>((const float*)d_X, stride_f, n, cube_size, g->grid_size,
-            g->n_cubes, g->d_cube_of, g->d_rank, g->d_count, g->d_status);
+            g->n_cubes, g->d_prev_pid, n_prev, g->d_cube_of, g->d_rank, g->d_count, g->d_status);
     k_tile_sum<<<g->n_tiles, BLOCK, 0, st>>>(g->d_count, g->d_tile_sums);
     k_scan<<<g->n_tiles, BLOCK, 0, st>>>(g->d_count, g->d_tile_sums, g->n_cubes, n, g->d_offs,
         g->d_cube_start, g->d_cube_end);
     if (n > 0) {
-        k_scatter<<<nb, BLOCK, 0, st>>>(
-            g->d_cube_of, g->d_rank, g->d_offs, n, g->d_arrival, g->d_cube_id);
+        k_scatter<<<nb, BLOCK, 0, st>>>(g->d_cube_of, g->d_rank, g->d_offs, n, g->d_prev_pid,
+            n_prev, g->d_arrival, g->d_cube_id);
         const bool gather = d_sorted_X != nullptr;
         if (gather && (entry_bytes < stride_bytes + 4 || entry_bytes % 4 || !d_sorted_v || !d_old_v))
             return (int)hipErrorInvalidValue;
@@ -396,7 +437,7 @@ int ya_grid_build_sorted(ya_grid* g, const void* d_X, size_t stride_bytes,
 #define YA_ORDER(NW)                                                                     \
     case NW:                                                                             \
         k_order<NW><<<nb, BLOCK, 0, st>>>(g->d_arrival, g->d_cube_id, g->d_offs, n,      \
-            g->d_point_id, (const float*)d_X, stride_f, (const float*)d_old_v,           \
+            g->d_point_id, g->d_prev_pid, (const float*)d_X, stride_f, (const float*)d_old_v, \
             (float*)d_sorted_X, entry_f, (float4*)d_sorted_v);                           \
         break;
         switch (gather ? stride_f : 0) {
@@ -420,6 +461,7 @@ int ya_grid_build_sorted(ya_grid* g, const void* d_X, size_t stride_bytes,
         }
 #undef YA_ORDER
     }
+    g->n_prev = n;
     return (int)hipGetLastError();
 }
 
