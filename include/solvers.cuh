@@ -286,29 +286,55 @@ inline float cutoff_squared(float cube_size)
     return t;
 }
 
-constexpr int STAGE_CELLS = 512;  // sorted cells staged in LDS at a time
+// Cells staged in LDS at a time (entry + old_v = 32 B per float3 cell) and the
+// per-thread hit-queue depth; 1024 * 32 B + 40 * 256 * 2 B = 52 KiB per
+// workgroup, i.e. three workgroups (12 wavefronts) per CU.
+template<typename Pt>
+struct Stage_cells {
+#ifndef YA_STAGE_CELLS
+#define YA_STAGE_CELLS 1024
+#endif
+    static constexpr int value =
+        sizeof(Entry<Pt>) <= 16 ? YA_STAGE_CELLS : (sizeof(Entry<Pt>) <= 32 ? YA_STAGE_CELLS * 3 / 4 : YA_STAGE_CELLS / 2);
+};
+#ifndef YA_QUEUE_DEPTH
+#define YA_QUEUE_DEPTH 40
+#endif
+constexpr int QUEUE_DEPTH = YA_QUEUE_DEPTH;
 
 // LDS-staged grid force.  A workgroup owns 256 consecutive sorted slots, i.e. a
 // run of cubes [c_lo, c_hi] along x.  For stencil row r every neighbour of every
 // cell of the workgroup lies in the contiguous slots
-// [offs[c_lo + off_r - 1], offs[c_hi + off_r + 2]), so the workgroup streams that
-// range through LDS in chunks (coalesced 16-byte loads) and each thread walks its
-// own sub-range [offs[c + off_r - 1], offs[c + off_r + 2]) out of LDS, rows in
-// the reference's d_nhood order and slots ascending: per-cell sums are
-// accumulated in the reference's order.
+// [offs[c_lo + off_r - 1], offs[c_hi + off_r + 2]); each thread's own candidates
+// are the sub-range [offs[c + off_r - 1], offs[c + off_r + 2]).  The nine rows are
+// handled as three planes (dz = 0, -1, +1: rows 0-2, 3-5, 6-8 of the reference's
+// d_nhood order).  Per plane the workgroup copies its three slot ranges into LDS
+// (coalesced 16-byte loads of {X, id} and old_v), then every thread
 //
-// Each thread handles its candidates 32 at a time in two phases so that the
-// expensive part runs with most lanes busy: phase 1 only tests d2 < cut2 and
-// records a 32-bit hit mask (~15 % of the 27-cube volume is inside the cut-off
-// sphere); phase 2 walks the set bits and evaluates distance, functor, friction
-// and the old_v term.
+//   phase 1  walks its candidates in the reference's order testing d2 < cut2
+//            only, and appends the LDS index of each hit (~15 % of the 27-cube
+//            volume lies inside the cut-off sphere) to a per-thread FIFO in LDS;
+//   phase 2  drains the FIFO: distance, functor, friction, old_v term.
+//
+// Both loops run until the slowest lane of the wavefront is done, so phase 2 is
+// kept dense by draining only once per plane (or when a FIFO could overflow):
+// a lane's hit count summed over a plane varies far less across the wavefront
+// than its hit count within one 32-candidate stretch.  Order is preserved
+// (FIFO), so every per-cell sum is accumulated in the reference's order.
 template<typename Pt, Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction>
 __global__ __launch_bounds__(FORCE_BLOCK) void grid_force(const int n,
     const Entry<Pt>* __restrict__ sorted, const float4* __restrict__ sorted_v,
     const int* __restrict__ cube_id, const int* __restrict__ offs, const int gs,
     const int n_cubes, const float cut2, Pt* __restrict__ d_dX, const bool has_gen)
 {
-    __shared__ Entry<Pt> sh[STAGE_CELLS];
+    constexpr int CAP = Stage_cells<Pt>::value;
+    __shared__ Entry<Pt> sh_e[CAP + 4];  // +4: phase 1 reads whole groups of four
+    __shared__ float4 sh_v[CAP];
+    __shared__ unsigned short sh_q[QUEUE_DEPTH * FORCE_BLOCK];
+    // LDS (address space 3) FIFO pointers: 32-bit address arithmetic in the hot loops
+    using Lds_u16 = __attribute__((address_space(3))) unsigned short;
+    Lds_u16* const q_base = (Lds_u16*)sh_q + threadIdx.x;          // this lane's FIFO, stride 256
+    Lds_u16* const q_high = q_base + (QUEUE_DEPTH - 4) * FORCE_BLOCK;  // "nearly full" mark
 
     const int s0 = blockIdx.x * FORCE_BLOCK;
     const int s = s0 + threadIdx.x;
@@ -327,50 +353,111 @@ __global__ __launch_bounds__(FORCE_BLOCK) void grid_force(const int n,
     Pt F = ya::zero<Pt>();
     float3 sum_v{0.f, 0.f, 0.f};
     float sum_friction = 0;
+    Lds_u16* q_tail = q_base;
+    asm volatile("" : "+v"(q_tail));
 
-    for (int row = 0; row < 9; row++) {
-        const int off = stencil_row_offset(row, gs);
-        const int wg_begin = offs[min(max(c_lo + off - 1, 0), n_cubes)];
-        const int wg_end = offs[min(max(c_hi + off + 2, 0), n_cubes)];
-        const int k_begin = offs[min(max(c + off - 1, 0), n_cubes)];
-        const int k_end = active ? offs[min(max(c + off + 2, 0), n_cubes)] : k_begin;
+    // Phase 2: drain this lane's FIFO (wavefront-wide loop, one code site).
+    auto drain = [&]() {
+        const int count = (int)(q_tail - q_base) / FORCE_BLOCK;
+        q_tail = q_base;
+        asm volatile("" : "+v"(q_tail));  // keep the tail an address, not base + count
+        int t_next = q_base[0];  // read one hit ahead: one LDS latency per trip, not two
+        for (int q = 0; q < count; q++) {
+            const int t = t_next;
+            t_next = q_base[min(q + 1, QUEUE_DEPTH - 1) * FORCE_BLOCK];
+            const Entry<Pt> other = sh_e[t];
+            const float4 v = sh_v[t];
+            Pt r = Xi - other.X;
+            float dist = dist3(r.x, r.y, r.z);
+            const int j = other.id;
+            F += pw_int(Xi, r, dist, i, j);
+            float friction = pw_friction(Xi, r, dist, i, j);
+            sum_friction += friction;
+            if (friction != 0) {
+                sum_v.x += friction * v.x;
+                sum_v.y += friction * v.y;
+                sum_v.z += friction * v.z;
+            }
+        }
+    };
+    auto dist2_to = [&](const int t) {
+        const float dx = Xi.x - sh_e[t].X.x;
+        const float dy = Xi.y - sh_e[t].X.y;
+        const float dz = Xi.z - sh_e[t].X.z;
+        return fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+    };
 
-        for (int chunk = wg_begin; chunk < wg_end; chunk += STAGE_CELLS) {
-            const int chunk_n = min(STAGE_CELLS, wg_end - chunk);
+    for (int plane = 0; plane < 3; plane++) {
+        // The plane's three rows, concatenated: row r occupies [v0[r], v0[r+1]).
+        int wg_begin[3], v0[4], k_begin[3], k_end[3];
+        v0[0] = 0;
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            const int off = stencil_row_offset(3 * plane + r, gs);
+            // The reference indexes cube_start/end without bounds checks
+            // (solvers.cuh:444); out-of-grid cubes are treated as empty here.
+            wg_begin[r] = offs[min(max(c_lo + off - 1, 0), n_cubes)];
+            v0[r + 1] = v0[r] + offs[min(max(c_hi + off + 2, 0), n_cubes)] - wg_begin[r];
+            k_begin[r] = offs[min(max(c + off - 1, 0), n_cubes)];
+            k_end[r] = active ? offs[min(max(c + off + 2, 0), n_cubes)] : k_begin[r];
+        }
+        const int total = v0[3];
+
+        for (int chunk = 0; chunk < total; chunk += CAP) {
+            const int chunk_n = min(CAP, total - chunk);
             __syncthreads();
-            for (int t = threadIdx.x; t < chunk_n; t += FORCE_BLOCK) sh[t] = sorted[chunk + t];
+            for (int t = threadIdx.x; t < chunk_n; t += FORCE_BLOCK) {
+                const int v = chunk + t;
+                const int shift = v >= v0[2] ? wg_begin[2] - v0[2]
+                                             : (v >= v0[1] ? wg_begin[1] - v0[1] : wg_begin[0]);
+                sh_e[t] = sorted[v + shift];
+                sh_v[t] = sorted_v[v + shift];
+            }
             __syncthreads();
 
-            const int a = max(k_begin, chunk);
-            const int b = min(k_end, chunk + chunk_n);
-            for (int base = a; base < b; base += 32) {
-                const Entry<Pt>* cand = sh + (base - chunk);
-                const int m = min(32, b - base);
-                unsigned hits = 0;
-                for (int t = 0; t < m; t++) {
-                    const float dx = Xi.x - cand[t].X.x;
-                    const float dy = Xi.y - cand[t].X.y;
-                    const float dz = Xi.z - cand[t].X.z;
-                    const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-                    hits |= (d2 < cut2 ? 1u : 0u) << t;
-                }
-                while (hits) {
-                    const int t = __builtin_ctz(hits);
-                    hits &= hits - 1;
-                    const Entry<Pt> other = cand[t];
-                    Pt r = Xi - other.X;
-                    float dist = dist3(r.x, r.y, r.z);
-                    const int j = other.id;
-                    F += pw_int(Xi, r, dist, i, j);
-                    float friction = pw_friction(Xi, r, dist, i, j);
-                    sum_friction += friction;
-                    if (friction != 0) {
-                        float4 v = sorted_v[base + t];
-                        sum_v.x += friction * v.x;
-                        sum_v.y += friction * v.y;
-                        sum_v.z += friction * v.z;
+            // One wavefront-uniform loop over the plane's rows.  Phase 1: each lane
+            // walks its candidates of the current row, four per trip (their LDS reads
+            // in flight together), until done or its FIFO is nearly full; when every
+            // lane is done the wavefront moves to the next row; phase 2 drains the
+            // FIFOs when a lane is full or the plane is finished.
+            Lds_u16* const q_last = q_base + (QUEUE_DEPTH - 1) * FORCE_BLOCK;
+            int row = 0;
+            int t = max(k_begin[0] - wg_begin[0], chunk) - chunk;
+            int b = min(k_end[0] - wg_begin[0], chunk + chunk_n) - chunk;
+            while (true) {
+                while (t + 4 <= b && q_tail <= q_high) {
+                    float d2[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) d2[u] = dist2_to(t + u);
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        if (d2[u] < cut2) {
+                            *q_tail = (unsigned short)(t + u);
+                            q_tail += FORCE_BLOCK;
+                        }
                     }
+                    t += 4;
                 }
+                while (t < b && q_tail <= q_last && (t + 4 > b || q_tail > q_high)) {
+                    if (dist2_to(t) < cut2) {
+                        *q_tail = (unsigned short)t;
+                        q_tail += FORCE_BLOCK;
+                    }
+                    t++;
+                }
+                const bool row_done = !__any(t < b);
+                if (row_done && row < 2) {
+                    row++;
+                    const int kb = row == 1 ? k_begin[1] - wg_begin[1] + v0[1]
+                                            : k_begin[2] - wg_begin[2] + v0[2];
+                    const int ke = row == 1 ? k_end[1] - wg_begin[1] + v0[1]
+                                            : k_end[2] - wg_begin[2] + v0[2];
+                    t = max(kb, chunk) - chunk;
+                    b = min(ke, chunk + chunk_n) - chunk;
+                    continue;
+                }
+                drain();  // phase 2
+                if (row_done) break;
             }
         }
     }
