@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--dist", type=float, default=0.5, help="random_sphere spacing")
     ap.add_argument("--cpu-steps", type=int, default=2, help="oracle steps for cpu_baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--slab", action="store_true",
+                    help="use the z-slab path (ghost exchange + all-reduce) even on 1 GPU")
     ap.add_argument("--force-variant", type=int, default=1,
                     help="1 = LDS-staged grid_force (default), 0 = grid_force_direct (A/B)")
     return ap.parse_args()
@@ -79,6 +81,9 @@ def cpu_baseline(n, gs, dist, steps):
 
 def main():
     args = parse()
+    # RCCL prints a version banner on stdout; the contract is ONE JSON line there.
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -93,19 +98,18 @@ def main():
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the HIP engine has no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or args.slab:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from yalla_amd.solution import Solution
 
-    n = args.cells
-    gs = args.grid_size or grid_size_for(n, args.dist)
-    sim = Solution("springs_grid", n, gs, 1.0)
-    # Independent systems per rank (different seeds): Grid_solver partitions by
-    # independent cell sets; see DESIGN.md "Multi-GPU".
-    sim.random_sphere(args.dist, 42 + rank)
-    sim.set_param("force_variant", args.force_variant)
+    n = args.cells            # cells per GPU (weak scaling: the system grows with N)
+    n_total = n * world
+    gs = args.grid_size or grid_size_for(n_total, args.dist)
     dt = 0.001
 
     def barrier():
@@ -113,16 +117,52 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    sim.take_step(dt, args.warmup)
+    if world == 1 and not args.slab:
+        sim = Solution("springs_grid", n, gs, 1.0)
+        sim.random_sphere(args.dist, 42)
+        sim.set_param("force_variant", args.force_variant)
+
+        def advance(k):
+            sim.take_step(dt, k)
+    else:
+        # ONE system of n_total cells, cut into z-slabs, one slab per GPU, ghost
+        # layers exchanged point-to-point over xGMI each stage (yalla_amd/slab.py).
+        # Every rank regenerates the same initial state from the seed (host-side
+        # glibc rand(), as inits.cuh does) and keeps its own slab.
+        from yalla_amd import slab as slab_mod
+
+        with Solution("springs_tile", n_total) as whole:
+            whole.random_sphere(args.dist, 42)
+            X0 = whole.h_X[:n_total].copy()
+        bounds = slab_mod.slab_bounds(X0[:, 2], world)
+        my_slab = slab_mod.Slab("springs_grid", X0, rank, world, bounds, gs, cube_size=1.0,
+                                device=f"cuda:{local_rank}")
+        del X0
+        sim = my_slab.sim
+        sim.set_param("force_variant", args.force_variant)
+        comm = slab_mod.DistComm()
+
+        def advance(k):
+            for _ in range(k):
+                slab_mod.step([my_slab], comm, dt)
+
+    advance(args.warmup)
     barrier()
     sim.profile(True)
     t0 = time.perf_counter()
-    sim.take_step(dt, args.steps)
+    advance(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     force_ms, launches = sim.profile_read()
     sim.profile(False)
-    assert sim.get_d_n() == n
+    if world == 1 and not args.slab:
+        assert sim.get_d_n() == n
+        n_force = n
+    else:
+        n_force = my_slab.n_local   # own + ghost cells the last force launch saw
+        counts = torch.tensor([my_slab.n_own()], dtype=torch.int64, device="cuda")
+        dist.all_reduce(counts)
+        assert int(counts.item()) == n_total, "cells were lost or duplicated in migration"
 
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     if world > 1:
@@ -133,7 +173,7 @@ def main():
         total_cells = n * world
         value = total_cells * args.steps / elapsed
         force_s = force_ms / 1e3 / max(launches, 1)
-        achieved = n * FORCE_BYTES_PER_CELL / force_s / 1e9
+        achieved = n_force * FORCE_BYTES_PER_CELL / force_s / 1e9
         out = {
             "metric": "cell-updates/sec at 1M cells (Grid_solver)",
             "value": value,
@@ -146,7 +186,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic: random_sphere(%g) seed 42+rank, glibc rand()" % args.dist,
+            "data": "synthetic: random_sphere(%g) seed 42, glibc rand()" % args.dist,
             "config": {
                 "workload": "Solution<float3, Grid_solver>::take_step<spring> (examples/springs.cu "
                             "functor, friction_w_neighbour), dt 0.001",
@@ -154,7 +194,8 @@ def main():
                 "total_cells": total_cells,
                 "grid_size": gs,
                 "cube_size": 1.0,
-                "parallelism": "1 GPU" if world == 1 else f"{world} independent systems",
+                "parallelism": "1 GPU" if world == 1 else
+                               f"{world} z-slabs of one {n_total}-cell system, ghost exchange via RCCL send/recv",
             },
             "roofline": {
                 "bound": "hbm",
@@ -164,7 +205,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": None,
-                "bytes_per_launch": n * FORCE_BYTES_PER_CELL,
+                "bytes_per_launch": n_force * FORCE_BYTES_PER_CELL,
                 "avg_launch_us": force_s * 1e6,
                 "launches": launches,
                 "whole_step_achieved_GBs": STEP_BYTES_PER_CELL * value / world / 1e9,
@@ -172,8 +213,11 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n, gs, args.dist, args.cpu_steps)
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
-    if world > 1:
+        os.dup2(2, 1)
+    if world > 1 or args.slab:
         dist.destroy_process_group()
 
 

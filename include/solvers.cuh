@@ -235,7 +235,8 @@ template<typename Pt, Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_
 __global__ __launch_bounds__(FORCE_BLOCK) void grid_force_direct(const int n,
     const Entry<Pt>* __restrict__ sorted, const float4* __restrict__ sorted_v,
     const int* __restrict__ cube_id, const int* __restrict__ offs, const int gs,
-    const int n_cubes, const float cube_size, Pt* __restrict__ d_dX, const bool has_gen)
+    const int n_cubes, const float cube_size, Pt* __restrict__ d_dX, const bool has_gen,
+    const int n_active)
 {
     const int s = blockIdx.x * FORCE_BLOCK + threadIdx.x;
     if (s >= n) return;
@@ -243,6 +244,7 @@ __global__ __launch_bounds__(FORCE_BLOCK) void grid_force_direct(const int n,
     const Entry<Pt> self = sorted[s];
     const Pt Xi = self.X;
     const int i = self.id;
+    if (i >= n_active) return;  // ghost cell of a slab decomposition: no force needed
     const int c = cube_id[s];
     Pt F = ya::zero<Pt>();
     float3 sum_v{0.f, 0.f, 0.f};
@@ -325,7 +327,8 @@ template<typename Pt, Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_
 __global__ __launch_bounds__(FORCE_BLOCK) void grid_force(const int n,
     const Entry<Pt>* __restrict__ sorted, const float4* __restrict__ sorted_v,
     const int* __restrict__ cube_id, const int* __restrict__ offs, const int gs,
-    const int n_cubes, const float cut2, Pt* __restrict__ d_dX, const bool has_gen)
+    const int n_cubes, const float cut2, Pt* __restrict__ d_dX, const bool has_gen,
+    const int n_active)
 {
     constexpr int CAP = Stage_cells<Pt>::value;
     __shared__ Entry<Pt> sh_e[CAP + 4];  // +4: phase 1 reads whole groups of four
@@ -338,7 +341,7 @@ __global__ __launch_bounds__(FORCE_BLOCK) void grid_force(const int n,
 
     const int s0 = blockIdx.x * FORCE_BLOCK;
     const int s = s0 + threadIdx.x;
-    const bool active = s < n;
+    bool active = s < n;
     const int c_lo = cube_id[s0];
     const int c_hi = cube_id[min(s0 + FORCE_BLOCK, n) - 1];
 
@@ -349,7 +352,9 @@ __global__ __launch_bounds__(FORCE_BLOCK) void grid_force(const int n,
         Xi = self.X;
         i = self.id;
         c = cube_id[s];
+        active = i < n_active;  // ghost cells of a slab decomposition get no force
     }
+    if (!__syncthreads_or(active)) return;  // a workgroup of ghosts only
     Pt F = ya::zero<Pt>();
     float3 sum_v{0.f, 0.f, 0.f};
     float sum_friction = 0;
@@ -657,31 +662,54 @@ protected:
         return d_fix;
     }
 
+    // The three pieces of a stage (stage 1 works on d_X -> d_dX, stage 2 on
+    // d_X1 -> d_dX1).  take_step composes them; a z-slab decomposition calls
+    // them one by one with a ghost exchange and an all-reduce in between
+    // (n = own + ghost cells, n_active = own cells).
+    template<Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction>
+    void stage_rhs(int stage, int n, int n_active, Generic_forces<Pt>& gen_forces)
+    {
+        Pt* d_in = stage == 1 ? d_X : d_X1;
+        Pt* d_rhs = stage == 1 ? d_dX : d_dX1;
+        const bool has_gen = !ya::is_no_gen_forces<Pt>(gen_forces);
+        if (has_gen) {
+            YA_CHECK(ya_memset_async(d_rhs, 0, (size_t)n * sizeof(Pt), nullptr));
+            gen_forces(n, d_in, d_rhs);
+        }
+        Computer<Pt>::template pwints<pw_int, pw_friction>(
+            n, d_in, d_old_v, d_rhs, has_gen, n_active);
+    }
+    // sum and mean of the stage's right-hand side over the first n points, left on
+    // the device as {mean[n_floats], sum[n_floats]}
+    const float* stage_sum(int stage, int n)
+    {
+        YA_CHECK(ya_reduce_mean(
+            stage == 1 ? d_dX : d_dX1, n_floats, n, d_mean, d_workspace, nullptr));
+        return d_mean;
+    }
+    void stage_update(int stage, int n, float dt, const float* d_fix_velocity)
+    {
+        const int blocks = (n + ya::UPDATE_BLOCK - 1) / ya::UPDATE_BLOCK;
+        if (stage == 1)
+            euler_step<<<blocks, ya::UPDATE_BLOCK>>>(n, dt, d_X, d_fix_velocity, d_dX, d_X1);
+        else
+            heun_step<<<blocks, ya::UPDATE_BLOCK>>>(
+                n, dt, d_dX, d_fix_velocity, d_dX1, d_X, d_old_v);
+    }
+
     template<Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction>
     void take_step(float dt, Generic_forces<Pt> gen_forces)
     {
         const int n = get_d_n();
         if (n <= 0) return;
-        const bool has_gen = !ya::is_no_gen_forces<Pt>(gen_forces);
-        const int blocks = (n + ya::UPDATE_BLOCK - 1) / ya::UPDATE_BLOCK;
 
         // 1st stage
-        if (has_gen) {
-            YA_CHECK(ya_memset_async(d_dX, 0, (size_t)n * sizeof(Pt), nullptr));
-            gen_forces(n, d_X, d_dX);
-        }
-        Computer<Pt>::template pwints<pw_int, pw_friction>(n, d_X, d_old_v, d_dX, has_gen);
-        const float* fix_dX = fix_velocity(n, d_dX, fix_com or fix_com_z, fix_com_z);
-        euler_step<<<blocks, ya::UPDATE_BLOCK>>>(n, dt, d_X, fix_dX, d_dX, d_X1);
+        stage_rhs<pw_int, pw_friction>(1, n, n, gen_forces);
+        stage_update(1, n, dt, fix_velocity(n, d_dX, fix_com or fix_com_z, fix_com_z));
 
         // 2nd stage
-        if (has_gen) {
-            YA_CHECK(ya_memset_async(d_dX1, 0, (size_t)n * sizeof(Pt), nullptr));
-            gen_forces(n, d_X1, d_dX1);
-        }
-        Computer<Pt>::template pwints<pw_int, pw_friction>(n, d_X1, d_old_v, d_dX1, has_gen);
-        const float* fix_dX1 = fix_velocity(n, d_dX1, fix_com, false);
-        heun_step<<<blocks, ya::UPDATE_BLOCK>>>(n, dt, d_dX, fix_dX1, d_dX1, d_X, d_old_v);
+        stage_rhs<pw_int, pw_friction>(2, n, n, gen_forces);
+        stage_update(2, n, dt, fix_velocity(n, d_dX1, fix_com, false));
     }
 };
 
@@ -700,8 +728,9 @@ protected:
     void check_status() {}
     template<Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction>
     void pwints(const int n, const Pt* __restrict__ d_X, const float3* __restrict__ d_old_v,
-        Pt* d_dX, const bool has_gen)
+        Pt* d_dX, const bool has_gen, const int n_active)
     {
+        assert(n_active == n);  // Tile_solver is single-GPU only (all pairs)
         profiler.mark();
         ya::tile_force<Pt, pw_int, pw_friction>
             <<<(n + ya::TILE_BLOCK - 1) / ya::TILE_BLOCK, ya::TILE_BLOCK>>>(
@@ -815,7 +844,7 @@ protected:
     void check_status() { grid.check_status(); }
     template<Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction>
     void pwints(const int n, const Pt* __restrict__ d_X, const float3* __restrict__ d_old_v,
-        Pt* d_dX, const bool has_gen)
+        Pt* d_dX, const bool has_gen, const int n_active)
     {
         grid.build_sorted(n, d_X, d_old_v, cube_size, d_sorted, d_sorted_v);
         const int blocks = (n + ya::FORCE_BLOCK - 1) / ya::FORCE_BLOCK;
@@ -823,11 +852,11 @@ protected:
         if (force_variant == 0)
             ya::grid_force_direct<Pt, pw_int, pw_friction><<<blocks, ya::FORCE_BLOCK>>>(n,
                 d_sorted, d_sorted_v, grid.d_cube_id, grid.offsets(), grid.grid_size,
-                grid.n_cubes, cube_size, d_dX, has_gen);
+                grid.n_cubes, cube_size, d_dX, has_gen, n_active);
         else
             ya::grid_force<Pt, pw_int, pw_friction><<<blocks, ya::FORCE_BLOCK>>>(n, d_sorted,
                 d_sorted_v, grid.d_cube_id, grid.offsets(), grid.grid_size, grid.n_cubes,
-                ya::cutoff_squared(cube_size), d_dX, has_gen);
+                ya::cutoff_squared(cube_size), d_dX, has_gen, n_active);
         profiler.mark();
     }
 };

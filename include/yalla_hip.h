@@ -29,7 +29,7 @@ extern "C" {
 /* The libraries are built with -fvisibility=hidden; only this C ABI is exported. */
 #pragma GCC visibility push(default)
 
-#define YA_ABI_VERSION 1
+#define YA_ABI_VERSION 2
 
 /* Status bits reported by ya_grid_status(). */
 #define YA_STATUS_OUT_OF_GRID 1 /* a cell's cube id fell outside [0, n_cubes):
@@ -109,6 +109,22 @@ int ya_reduce_mean(const void* d_v, int n_floats, int n, float* d_out,
 
 /* Size in bytes of the workspace ya_reduce_mean needs. */
 size_t ya_reduce_workspace_bytes(int n_floats);
+
+/* ---- Ordered selection and row gather (multi-GPU slab decomposition) ------ */
+
+/* Indices i in [0, n), ascending, of the points whose third float (z) satisfies
+ * z_min <= z < z_max, written to d_idx; their number to *d_count (device).
+ * Deterministic (two-pass count + ordered write, no atomics).  New relative to
+ * the reference, which is single-GPU; used to pick the ghost layer a z-slab
+ * sends to its neighbour and the cells that migrate (DESIGN.md "Multi-GPU"). */
+int ya_select_z(const void* d_X, size_t stride_bytes, int n, float z_min, float z_max,
+    int* d_idx, int* d_count, int* d_workspace, void* stream);
+size_t ya_select_workspace_bytes(int n_max);
+
+/* d_dst[k] = d_src[d_idx[k]] for k < min(*d_count, cap); rows of row_bytes
+ * (a multiple of 4) bytes.  The count stays on the device: no host round trip. */
+int ya_gather_rows(const void* d_src, size_t row_bytes, const int* d_idx, const int* d_count,
+    int cap, void* d_dst, void* stream);
 
 #pragma GCC visibility pop
 #ifdef __cplusplus

@@ -84,6 +84,29 @@ int ya_sim_get_prop(ya_sim* sim, const char* name, int* values, int n);
 /* Links of a model that has them: n_links pairs (a, b), then copy_to_device. */
 int ya_sim_set_links(ya_sim* sim, const int* ab, int n_links, float strength);
 
+/* ---- z-slab decomposition of a Grid_solver model over ranks.
+ * New relative to the reference (single-GPU).  A rank owns the cells with
+ * z in [z_lo, z_hi); local arrays hold own cells [0, n_own) then ghosts.  All
+ * buffers are device memory (host memory on the oracle) of ya_slab_*_bytes(cap)
+ * bytes: a 16-byte header {int count} and `cap` rows per field.  One stage is
+ *   pack_halo(dir 0 -> lower neighbour, 1 -> upper) ; exchange ; unpack_halo ;
+ *   stage_rhs ; stage_sum -> {sum[n_floats], n_own} ; all-reduce ; stage_update
+ * and after stage 2: migrate_pack ; exchange ; migrate_unpack.  The exchange
+ * itself (RCCL send/recv, all-reduce) is the caller's: yalla_amd/slab.py. */
+int ya_slab_init(ya_sim* sim, float z_lo, float z_hi, float halo_width, const int* global_ids);
+long ya_slab_halo_bytes(ya_sim* sim, int cap_cells);
+long ya_slab_migrate_bytes(ya_sim* sim, int cap_cells);
+int ya_slab_pack_halo(ya_sim* sim, int stage, int dir, void* d_buf, int cap_cells);
+/* returns the local cell count own + ghosts, or < 0 (-4 sender overflow, -5 no room) */
+int ya_slab_unpack_halo(ya_sim* sim, int stage, const void* d_buf_lo, const void* d_buf_hi, int cap_cells);
+int ya_slab_stage_rhs(ya_sim* sim, int stage);
+int ya_slab_stage_sum(ya_sim* sim, int stage, float* d_sum_and_count);
+int ya_slab_stage_update(ya_sim* sim, int stage, float dt, const float* d_total_sum_and_count);
+int ya_slab_migrate_pack(ya_sim* sim, void* d_buf_lo, void* d_buf_hi, int cap_cells);
+int ya_slab_migrate_unpack(ya_sim* sim, const void* d_buf_lo, const void* d_buf_hi, int cap_cells);
+int ya_slab_n_own(ya_sim* sim);
+int ya_slab_get_own(ya_sim* sim, float* X_host, int* global_ids_host);
+
 /* Oracle only: 0 = serial COM sum, 1 = the engine's documented tree order.
  * Returns -1 on the device build. */
 int ya_sim_set_reduce_order(ya_sim* sim, int order);

@@ -19,4 +19,44 @@ void ya_harness_random_sphere(float dist_to_nb, C& cells, unsigned seed)
     cells.copy_to_device();
 }
 
+// Backend operations of the z-slab decomposition, restated serially ("device"
+// memory is host memory).  Same contracts as include/yalla_hip.h's ya_select_z
+// and ya_gather_rows.
+namespace harness_ops {
+inline void* alloc(size_t bytes) { return calloc(1, bytes ? bytes : 4); }
+inline void release(void* p) { free(p); }
+inline size_t select_workspace_bytes(int) { return 4; }
+inline void select_z(const void* X, size_t stride, int n, float z_min, float z_max, int* idx,
+    int* count, int*)
+{
+    int m = 0;
+    for (int i = 0; i < n; i++) {
+        const float z = *(const float*)((const char*)X + (size_t)i * stride + 8);
+        if (z >= z_min && z < z_max) idx[m++] = i;
+    }
+    *count = m;
+}
+inline void gather_rows(const void* src, size_t row_bytes, const int* idx, const int* count, int cap,
+    void* dst)
+{
+    const int m = *count < cap ? *count : cap;
+    for (int k = 0; k < m; k++)
+        memcpy((char*)dst + (size_t)k * row_bytes, (const char*)src + (size_t)idx[k] * row_bytes,
+            row_bytes);
+}
+inline void copy(void* dst, const void* src, size_t bytes) { memmove(dst, src, bytes); }
+inline int read_int(const void* d) { return *(const int*)d; }
+inline void write_int(void* d, int v) { *(int*)d = v; }
+inline void mean_from_total(const float* total, int n_floats, float* fix)
+{
+    const float inv = (float)(1. / (double)total[n_floats]);
+    for (int k = 0; k < 3; k++) fix[k] = total[k] * inv;
+}
+inline void pack_sum(const float* sum, int n_floats, int n_own, float* out)
+{
+    for (int k = 0; k < n_floats; k++) out[k] = sum[k];
+    out[n_floats] = (float)n_own;
+}
+}  // namespace harness_ops
+
 #include "models_harness.inc"

@@ -296,7 +296,7 @@ public:
 protected:
     template<Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction>
     void pwints(const int n, const Pt* d_X, const float3* d_old_v, Pt* d_dX,
-        float3* d_sum_v, float* d_sum_friction)
+        float3* d_sum_v, float* d_sum_friction, int n_active = -1)
     {
         for (int i = 0; i < n; i++) {           // one "thread" per point
             Pt Xi = d_X[i];                      // :290-291
@@ -432,11 +432,13 @@ protected:
     int nhood[27];
     template<Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction>
     void pwints(int n, const Pt* d_X, const float3* d_old_v, Pt* d_dX,
-        float3* d_sum_v, float* d_sum_friction)
+        float3* d_sum_v, float* d_sum_friction, int n_active = -1)
     {
+        if (n_active < 0) n_active = n;
         grid.build(n, d_X, cube_size);  // :494
         for (int i = 0; i < n; i++) {   // thread i owns sorted slot i: :430-463
             int pi = grid.d_point_id[i];
+            if (pi >= n_active) continue;  // ghost cell of a slab decomposition (not in the reference)
             Pt Xi = d_X[pi];
             Pt F;
             memset(&F, 0, sizeof(Pt));
@@ -527,6 +529,46 @@ protected:
                 dX[i].x += sum_v[i].x / sum_friction[i];
                 dX[i].y += sum_v[i].y / sum_friction[i];
                 dX[i].z += sum_v[i].z / sum_friction[i];
+            }
+        }
+    }
+
+    // The pieces of one stage, for the z-slab decomposition (not in the reference,
+    // which is single-GPU): n = own + ghost cells, n_active = own cells.  They
+    // restate exactly the statements of take_step below, stage by stage.
+    template<Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction>
+    void stage_rhs(int stage, int n, int n_active, Generic_forces<Pt>& gen_forces)
+    {
+        Pt* in = stage == 1 ? d_X : d_X1;
+        Pt* rhs = stage == 1 ? d_dX : d_dX1;
+        memset(rhs, 0, (size_t)n * sizeof(Pt));
+        memset(d_sum_friction, 0, (size_t)n * sizeof(float));
+        memset(d_sum_v, 0, (size_t)n * sizeof(float3));
+        gen_forces(n, in, rhs);
+        Computer<Pt>::template pwints<pw_int, pw_friction>(
+            n, in, d_old_v, rhs, d_sum_v, d_sum_friction, n_active);
+        add_rhs(n_active, d_sum_v, d_sum_friction, rhs);
+    }
+    Pt stage_sum(int stage, int n)
+    {
+        return ya_oracle_reduce(stage == 1 ? d_dX : d_dX1, n, reduce_order);
+    }
+    void stage_update(int stage, int n, float dt, const float* fix)
+    {
+        for (int i = 0; i < n; i++) {
+            if (stage == 1) {  // euler_step :113-125
+                d_dX[i].x -= fix[0];
+                d_dX[i].y -= fix[1];
+                d_dX[i].z -= fix[2];
+                d_X1[i] = d_X[i] + d_dX[i] * dt;
+            } else {  // heun_step :127-144
+                d_dX1[i].x -= fix[0];
+                d_dX1[i].y -= fix[1];
+                d_dX1[i].z -= fix[2];
+                d_X[i] += (d_dX[i] + d_dX1[i]) * 0.5 * dt;
+                d_old_v[i].x = (d_dX[i].x + d_dX1[i].x) * 0.5;
+                d_old_v[i].y = (d_dX[i].y + d_dX1[i].y) * 0.5;
+                d_old_v[i].z = (d_dX[i].z + d_dX1[i].z) * 0.5;
             }
         }
     }

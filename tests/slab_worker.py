@@ -1,0 +1,43 @@
+"""One rank of the gloo slab test (launched by torch.distributed.run)."""
+import os
+import sys
+
+import numpy as np
+import torch.distributed as dist
+
+from conftest import build_oracle
+from yalla_amd import _ffi
+from yalla_amd import slab as slab_mod
+from yalla_amd.solution import Solution
+
+
+def main(out):
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    lib = _ffi.bind(build_oracle() if rank == 0 else None or build_oracle())
+    n, gs = 3000, 50
+    with Solution("springs_grid", n, gs, 1.0, lib=lib) as s:
+        s.random_sphere(0.5, 3)
+        X0 = s.h_X[:n].copy()
+    bounds = slab_mod.slab_bounds(X0[:, 2], world)
+    sl = slab_mod.Slab("springs_grid", X0, rank, world, bounds, gs, lib=lib, device="cpu")
+    comm = slab_mod.DistComm()
+    for _ in range(6):
+        slab_mod.step([sl], comm, 0.003)
+    gid, X = sl.own_cells()
+    parts = [None] * world
+    dist.gather_object((gid, X), parts if rank == 0 else None, dst=0)
+    if rank == 0:
+        full = np.zeros_like(X0)
+        count = 0
+        for g, x in parts:
+            full[g] = x
+            count += len(g)
+        assert count == n
+        np.savez(out, X0=X0, X=full)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])

@@ -45,6 +45,18 @@ MODELS_ABI = {
     "ya_sim_get_prop": (C.c_int, [_sim, C.c_char_p, _pi, C.c_int]),
     "ya_sim_set_links": (C.c_int, [_sim, _pi, C.c_int, C.c_float]),
     "ya_sim_set_reduce_order": (C.c_int, [_sim, C.c_int]),
+    "ya_slab_init": (C.c_int, [_sim, C.c_float, C.c_float, C.c_float, _pi]),
+    "ya_slab_halo_bytes": (C.c_long, [_sim, C.c_int]),
+    "ya_slab_migrate_bytes": (C.c_long, [_sim, C.c_int]),
+    "ya_slab_pack_halo": (C.c_int, [_sim, C.c_int, C.c_int, C.c_void_p, C.c_int]),
+    "ya_slab_unpack_halo": (C.c_int, [_sim, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
+    "ya_slab_stage_rhs": (C.c_int, [_sim, C.c_int]),
+    "ya_slab_stage_sum": (C.c_int, [_sim, C.c_int, C.c_void_p]),
+    "ya_slab_stage_update": (C.c_int, [_sim, C.c_int, C.c_float, C.c_void_p]),
+    "ya_slab_migrate_pack": (C.c_int, [_sim, C.c_void_p, C.c_void_p, C.c_int]),
+    "ya_slab_migrate_unpack": (C.c_int, [_sim, C.c_void_p, C.c_void_p, C.c_int]),
+    "ya_slab_n_own": (C.c_int, [_sim]),
+    "ya_slab_get_own": (C.c_int, [_sim, _pf, _pi]),
     "ya_sim_profile": (C.c_int, [_sim, C.c_int]),
     "ya_sim_profile_read": (C.c_int, [_sim, C.POINTER(C.c_double), _pi]),
 }
@@ -55,7 +67,7 @@ CORE_ABI = [
     "ya_memcpy_d2h", "ya_memcpy_d2d_async", "ya_device_synchronize", "ya_get_n",
     "ya_grid_create", "ya_grid_destroy", "ya_grid_arrays", "ya_grid_offsets",
     "ya_grid_build", "ya_grid_build_sorted", "ya_grid_status", "ya_reduce_mean",
-    "ya_reduce_workspace_bytes",
+    "ya_reduce_workspace_bytes", "ya_select_z", "ya_select_workspace_bytes", "ya_gather_rows",
 ]
 
 

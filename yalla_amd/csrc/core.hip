@@ -282,6 +282,77 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_final(
     }
 }
 
+// --- ordered selection ---------------------------------------------------------
+constexpr int SEL_ITEMS = 8;
+constexpr int SEL_TILE = BLOCK * SEL_ITEMS;
+
+__device__ __forceinline__ bool in_range(const float* __restrict__ X, int stride_f, int i, int n,
+    float z_min, float z_max)
+{
+    if (i >= n) return false;
+    const float z = X[(size_t)i * stride_f + 2];
+    return z >= z_min && z < z_max;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_select_count(const float* __restrict__ X, int stride_f,
+    int n, float z_min, float z_max, int* __restrict__ tile_counts)
+{
+    __shared__ int sh[4];
+    const int base = blockIdx.x * SEL_TILE + threadIdx.x * SEL_ITEMS;
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < SEL_ITEMS; k++) c += in_range(X, stride_f, base + k, n, z_min, z_max);
+    const int total = block_sum(c, sh);
+    if (threadIdx.x == 0) tile_counts[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_select_write(const float* __restrict__ X, int stride_f,
+    int n, float z_min, float z_max, const int* __restrict__ tile_counts, int* __restrict__ idx,
+    int* __restrict__ count)
+{
+    __shared__ int sh[4];
+    __shared__ int sh_wave[4];
+    int before = 0;
+    for (int t = threadIdx.x; t < (int)blockIdx.x; t += BLOCK) before += tile_counts[t];
+    before = block_sum(before, sh);
+
+    const int base = blockIdx.x * SEL_TILE + threadIdx.x * SEL_ITEMS;
+    bool keep[SEL_ITEMS];
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < SEL_ITEMS; k++) {
+        keep[k] = in_range(X, stride_f, base + k, n, z_min, z_max);
+        c += keep[k];
+    }
+    int incl = c;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int o = 1; o < 64; o <<= 1) {
+        int up = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += up;
+    }
+    if (lane == 63) sh_wave[w] = incl;
+    __syncthreads();
+    int wave_off = 0;
+    for (int k = 0; k < w; k++) wave_off += sh_wave[k];
+    int out = before + wave_off + incl - c;
+#pragma unroll
+    for (int k = 0; k < SEL_ITEMS; k++)
+        if (keep[k]) idx[out++] = base + k;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == BLOCK - 1) *count = out;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_gather_rows(const float* __restrict__ src, int row_f,
+    const int* __restrict__ idx, const int* __restrict__ count, int cap, float* __restrict__ dst)
+{
+    const int m = min(*count, cap);
+    // one thread per float of the output
+    for (long e = (long)blockIdx.x * BLOCK + threadIdx.x; e < (long)m * row_f;
+         e += (long)gridDim.x * BLOCK) {
+        const int k = (int)(e / row_f), f = (int)(e % row_f);
+        dst[e] = src[(size_t)idx[k] * row_f + f];
+    }
+}
+
 template<int NW>
 int launch_reduce(const float* v, int n, float* out, float* ws, hipStream_t st)
 {
@@ -478,6 +549,39 @@ int ya_grid_status(ya_grid* g, int* bits, int clear)
     YA_TRY(hipMemcpy(bits, g->d_status, sizeof(int), hipMemcpyDeviceToHost));
     if (clear && *bits) YA_TRY(hipMemset(g->d_status, 0, sizeof(int)));
     return 0;
+}
+
+size_t ya_select_workspace_bytes(int n_max)
+{
+    return (size_t)(ceil_div(n_max > 0 ? n_max : 1, SEL_TILE) + 1) * sizeof(int);
+}
+
+int ya_select_z(const void* d_X, size_t stride_bytes, int n, float z_min, float z_max, int* d_idx,
+    int* d_count, int* d_ws, void* stream)
+{
+    if (n < 0 || stride_bytes < 12 || stride_bytes % 4) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) return (int)hipMemsetAsync(d_count, 0, sizeof(int), st);
+    const int tiles = ceil_div(n, SEL_TILE);
+    const int stride_f = (int)(stride_bytes / 4);
+    k_select_count<<<tiles, BLOCK, 0, st>>>((const float*)d_X, stride_f, n, z_min, z_max, d_ws);
+    k_select_write<<<tiles, BLOCK, 0, st>>>(
+        (const float*)d_X, stride_f, n, z_min, z_max, d_ws, d_idx, d_count);
+    return (int)hipGetLastError();
+}
+
+int ya_gather_rows(const void* d_src, size_t row_bytes, const int* d_idx, const int* d_count,
+    int cap, void* d_dst, void* stream)
+{
+    if (row_bytes == 0 || row_bytes % 4 || cap < 0) return (int)hipErrorInvalidValue;
+    if (cap == 0) return 0;
+    const int row_f = (int)(row_bytes / 4);
+    long floats = (long)cap * row_f;
+    int blocks = (int)((floats + BLOCK - 1) / BLOCK);
+    if (blocks > 4096) blocks = 4096;
+    k_gather_rows<<<blocks, BLOCK, 0, (hipStream_t)stream>>>(
+        (const float*)d_src, row_f, d_idx, d_count, cap, (float*)d_dst);
+    return (int)hipGetLastError();
 }
 
 size_t ya_reduce_workspace_bytes(int n_floats)
