@@ -7,6 +7,7 @@
 
 #include "model_functors.h"
 
+#define YA_ZERO(d, bytes) memset((d), 0, (bytes))
 #define YA_IS_DEVICE 0
 #define YA_D2H(h, d, bytes) memcpy((h), (d), (bytes))
 #define YA_H2D(d, h, bytes) memcpy((d), (h), (bytes))

@@ -183,6 +183,13 @@ typename std::enable_if<Is_vector<Pt>::value, Pt>::type operator/(
     return q;
 }
 
+// utils.cuh:22-26
+template<typename Pt_a, typename Pt_b>
+float dot_product(Pt_a a, Pt_b b)
+{
+    return a.x * b.x + a.y * b.y + a.z * b.z;
+}
+
 // Device intrinsics a model functor may use, restated for the host.
 inline float ya_dist3(float x, float y, float z)
 {
@@ -682,6 +689,29 @@ public:
     {
         return Solver<Pt>::template take_step<pw_int, pw_friction>(dt, gen_forces);
     }
+};
+
+// ---------------------------------------------------------------------------
+// Property: property.cuh:1-34 ("device" copy = a second host array)
+// ---------------------------------------------------------------------------
+template<typename Prop = int>
+struct Property {
+    Prop* h_prop;
+    Prop* d_prop;
+    const int n_max;
+    Property(int n_max) : n_max{n_max}
+    {
+        h_prop = (Prop*)calloc(n_max, sizeof(Prop));
+        d_prop = (Prop*)calloc(n_max, sizeof(Prop));
+    }
+    ~Property()
+    {
+        free(h_prop);
+        free(d_prop);
+    }
+    Property(const Property&) = delete;
+    void copy_to_device() { memcpy(d_prop, h_prop, (size_t)n_max * sizeof(Prop)); }
+    void copy_to_host() { memcpy(h_prop, d_prop, (size_t)n_max * sizeof(Prop)); }
 };
 
 // ---------------------------------------------------------------------------

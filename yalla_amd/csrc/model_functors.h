@@ -7,6 +7,8 @@
 // the public header API.  Each functor cites the reference model it restates.
 #pragma once
 
+#include "polarity.cuh"
+
 #ifdef YA_ORACLE
 #define YA_MODEL_VAR static
 #define YA_SET_VAR(var, value) ((var) = (value))
@@ -112,5 +114,149 @@ __device__ inline void custom_force(
     atomicAdd(&d_dX[a].w, -1.f);
     atomicAdd(&d_dX[b].w, 1.f);
 }
+
+// --- passive growth: examples/passive_growth.cu:16-91 (mesenchyme enveloped by a
+// polarized epithelium; Po_cell; per-cell neighbour counters updated from inside
+// the functor, one thread per cell i).  The example's compile-time constants are
+// kept; its cuRAND draws are replaced by a counter-based hash so that the CPU
+// oracle and the GPU make the same proliferation decisions. -----------------------
+enum Cell_types { mesenchyme, epithelium };
+YA_MODEL_VAR int* d_type;
+YA_MODEL_VAR int* d_mes_nbs;  // number of mesenchymal neighbours
+YA_MODEL_VAR int* d_epi_nbs;
+
+__device__ inline Po_cell relu_w_epithelium(Po_cell Xi, Po_cell r, float dist, int i, int j)
+{
+    const auto r_max = 1;
+    Po_cell dF{0};
+    if (i == j) return dF;
+    if (dist > r_max) return dF;
+
+    float F;
+    if (d_type[i] == d_type[j]) {
+        F = fmaxf(0.7 - dist, 0) * 2 - fmaxf(dist - 0.8, 0);
+    } else {
+        F = fmaxf(0.8 - dist, 0) * 2 - fmaxf(dist - 0.9, 0);
+    }
+    dF.x = r.x * F / dist;
+    dF.y = r.y * F / dist;
+    dF.z = r.z * F / dist;
+
+    if (d_type[j] == mesenchyme)
+        d_mes_nbs[i] += 1;
+    else
+        d_epi_nbs[i] += 1;
+
+    if (d_type[i] == mesenchyme or d_type[j] == mesenchyme) return dF;
+
+    dF += bending_force(Xi, r, dist) * 0.15;
+    return dF;
+}
+
+// Uniform in (0, 1] from (seed, step, cell, draw): lowbias32-style integer mix.
+__device__ __host__ inline float hash_uniform(unsigned seed, unsigned step, unsigned i, unsigned k)
+{
+    unsigned x = seed ^ (step * 0x9E3779B9u) ^ (i * 0x85EBCA6Bu) ^ (k * 0xC2B2AE35u);
+    x ^= x >> 16;
+    x *= 0x7FEB352Du;
+    x ^= x >> 15;
+    x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return ((x >> 8) + 1) * (1.0f / 16777216.0f);
+}
+
+// Does cell i divide this step?  (passive_growth.cu:67-78)
+__device__ __host__ inline bool pg_divides(float rate, unsigned seed, unsigned step, int i,
+    const int* type, const int* mes_nbs, const int* epi_nbs)
+{
+    if (type[i] == mesenchyme) return !(hash_uniform(seed, step, i, 0) > rate);
+    return !(epi_nbs[i] > mes_nbs[i]);
+}
+
+// Daughter n of mother i (passive_growth.cu:80-90).
+__device__ __host__ inline void pg_divide(double mean_dist, unsigned seed, unsigned step, int i,
+    int n, Po_cell* X, float3* old_v, int* type, int* mes_nbs, int* epi_nbs)
+{
+    auto theta = acosf(2. * hash_uniform(seed, step, i, 1) - 1);
+    auto phi = hash_uniform(seed, step, i, 2) * 2 * M_PI;
+    X[n].x = X[i].x + mean_dist / 4 * sinf(theta) * cosf(phi);
+    X[n].y = X[i].y + mean_dist / 4 * sinf(theta) * sinf(phi);
+    X[n].z = X[i].z + mean_dist / 4 * cosf(theta);
+    X[n].theta = X[i].theta;
+    X[n].phi = X[i].phi;
+    type[n] = type[i];
+    mes_nbs[n] = 0;
+    epi_nbs[n] = 0;
+    old_v[n] = old_v[i];
+}
+
+// proliferate (passive_growth.cu:60-91), made reproducible: mothers are the cells
+// i < n that pg_divides() selects; daughters are appended in ascending mother
+// order (the example appends in atomicAdd arrival order).
+#ifdef YA_ORACLE
+inline void pg_proliferate(float rate, double mean_dist, unsigned seed, unsigned step, int n,
+    Po_cell* X, float3* old_v, int* d_n, int* type, int* mes_nbs, int* epi_nbs, int*, int n_max)
+{
+    int n_new = n;
+    for (int i = 0; i < n; i++) {
+        if (!pg_divides(rate, seed, step, i, type, mes_nbs, epi_nbs)) continue;
+        assert(n_new < n_max);
+        pg_divide(mean_dist, seed, step, i, n_new++, X, old_v, type, mes_nbs, epi_nbs);
+    }
+    *d_n = n_new;
+}
+#else
+__global__ void pg_flag(float rate, unsigned seed, unsigned step, int n, const int* type,
+    const int* mes_nbs, const int* epi_nbs, int* flag)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flag[i] = pg_divides(rate, seed, step, i, type, mes_nbs, epi_nbs);
+}
+// exclusive prefix of the flags by ONE workgroup (model-side helper, not a hot path)
+__global__ __launch_bounds__(1024) void pg_scan(int n, int* flag_to_offset, int* d_n, int n_max)
+{
+    __shared__ int sh[1024];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int f = i < n ? flag_to_offset[i] : 0;
+        sh[threadIdx.x] = f;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            const int v = (int)threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += v;
+            __syncthreads();
+        }
+        const int incl = sh[threadIdx.x];
+        if (i < n) flag_to_offset[i] = f ? carry + incl - f : -1;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        D_ASSERT(n + carry <= n_max);
+        *d_n = n + carry;
+    }
+}
+__global__ void pg_daughters(double mean_dist, unsigned seed, unsigned step, int n, const int* offset,
+    Po_cell* X, float3* old_v, int* type, int* mes_nbs, int* epi_nbs)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || offset[i] < 0) return;
+    pg_divide(mean_dist, seed, step, i, n + offset[i], X, old_v, type, mes_nbs, epi_nbs);
+}
+inline void pg_proliferate(float rate, double mean_dist, unsigned seed, unsigned step, int n,
+    Po_cell* X, float3* old_v, int* d_n, int* type, int* mes_nbs, int* epi_nbs, int* scratch,
+    int n_max)
+{
+    const int blocks = (n + 255) / 256;
+    pg_flag<<<blocks, 256>>>(rate, seed, step, n, type, mes_nbs, epi_nbs, scratch);
+    pg_scan<<<1, 1024>>>(n, scratch, d_n, n_max);
+    pg_daughters<<<blocks, 256>>>(mean_dist, seed, step, n, scratch, X, old_v, type, mes_nbs, epi_nbs);
+}
+#endif
 
 }  // namespace models

@@ -12,6 +12,7 @@
 
 #include "model_functors.h"
 
+#define YA_ZERO(d, bytes) YA_CHECK(ya_memset_async((d), 0, (bytes), nullptr))
 #define YA_IS_DEVICE 1
 #define YA_D2H(h, d, bytes) YA_CHECK(ya_memcpy_d2h((h), (d), (bytes)))
 #define YA_H2D(d, h, bytes) YA_CHECK(ya_memcpy_h2d((d), (h), (bytes)))
