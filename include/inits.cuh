@@ -152,3 +152,69 @@ void relaxed_cuboid(float dist_to_nb, float3 minimum, float3 maximum,
     const int steps = n <= 3000 ? 1000 : (n <= 12000 ? 2000 : 3000);
     ya::relax_and_rescale(scale, points, steps, 15000);
 }
+
+
+// Hexagonal patch in the z = 0 plane, filled ring by ring around a centre cell:
+// ring i holds 6 corner cells at distance i * dist_to_nb (first one on the +y
+// axis, going counter-clockwise) with i - 1 evenly spaced cells on each edge
+// between consecutive corners (inits.cuh:158-215).  Stops when h_n cells exist.
+template<typename Pt, template<typename> class Solver>
+void regular_hexagon(float dist_to_nb, Solution<Pt, Solver>& points, unsigned int n_0 = 0)
+{
+    assert(n_0 < *points.h_n);
+
+    const unsigned n = *points.h_n;
+    unsigned placed = n_0;
+    auto place = [&](float x, float y) {
+        points.h_X[placed].x = x;
+        points.h_X[placed].y = y;
+        points.h_X[placed].z = 0.f;
+        placed++;
+        return placed == n;
+    };
+    const float beta = M_PI / 3.f;
+    bool full = place(0.f, 0.f);
+    for (int ring = 1; !full; ring++) {
+        for (int corner = 0; corner < 6 && !full; corner++) {
+            const float angle = beta * corner;
+            const float3 p{-dist_to_nb * ring * sinf(angle), dist_to_nb * ring * cosf(angle), 0.f};
+            full = place(p.x, p.y);
+            const int n_between = ring - 1;
+            if (full || n_between < 1) continue;
+            const float next_angle = beta * (corner + 1);
+            const float3 q{
+                -dist_to_nb * ring * sinf(next_angle), dist_to_nb * ring * cosf(next_angle), 0.f};
+            float3 v = q - p;
+            const auto modulus = sqrt(pow(v.x, 2) + pow(v.y, 2));
+            v = v * (1.f / modulus);
+            for (int k = 1; k <= n_between && !full; k++) {
+                const float3 u = v * modulus * (float(k) / float(n_between + 1));
+                full = place(p.x + u.x, p.y + u.y);
+            }
+        }
+    }
+    points.copy_to_device();
+}
+
+// Rows of nx cells in the z = 0 plane on a triangular lattice: row spacing
+// sqrt(3)/2 * dist_to_nb, odd rows shifted by half a spacing (inits.cuh:217-247).
+template<typename Pt, template<typename> class Solver>
+void regular_rectangle(
+    float dist_to_nb, int nx, Solution<Pt, Solver>& points, unsigned int n_0 = 0)
+{
+    assert(n_0 < *points.h_n);
+
+    const unsigned n = *points.h_n;
+    unsigned placed = n_0;
+    for (int row = 0; placed < n; row++) {
+        const float y = row * sqrt(pow(dist_to_nb, 2) - pow(dist_to_nb / 2.f, 2));
+        const float shift = row % 2 != 0 ? dist_to_nb / 2.f : 0.0f;
+        for (int col = 0; col < nx && placed < n; col++) {
+            points.h_X[placed].x = shift + col * dist_to_nb;
+            points.h_X[placed].y = y;
+            points.h_X[placed].z = 0.0f;
+            placed++;
+        }
+    }
+    points.copy_to_device();
+}

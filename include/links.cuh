@@ -149,3 +149,84 @@ void link_forces(Links& links, const Pt* __restrict__ d_X, Pt* d_dX)
 {
     link_forces<Pt, linear_force<Pt>>(links, d_X, d_dX);
 }
+
+
+// Solid wall normal to z whose position is the z of the "wall node" wall_idx
+// (links.cuh:142-228).  Cells closer than 1 to the wall plane are pushed by a
+// relu force; the opposite force and the number of interactions are accumulated
+// on the wall node, whose velocity is then averaged over its interactions.
+template<typename Pt>
+using Wall_force =
+    void(const Pt* __restrict__ d_X, const int i, const int wall_idx, Pt* d_dX, int* d_nints);
+
+template<typename Pt>
+__device__ void xy_wall_relu_force(
+    const Pt* __restrict__ d_X, const int i, const int wall_idx, Pt* d_dX, int* d_nints)
+{
+    const auto Xwall = d_X[wall_idx].z;
+    const auto dist_wall = fabs(d_X[i].z - Xwall);
+    if (dist_wall < 1.0f) {
+        const auto F = fmaxf(0.8 - dist_wall, 0) - fmaxf(dist_wall - 0.8, 0);
+        d_dX[i].z += F;
+        atomicAdd(&d_dX[wall_idx].z, -F);
+        atomicAdd(&d_nints[wall_idx], 1);
+    }
+}
+
+template<typename Pt, Wall_force<Pt> force>
+__global__ __launch_bounds__(256) void wall(
+    const Pt* __restrict__ d_X, Pt* d_dX, int n, int wall_idx, int* d_nints)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (i == wall_idx) return;
+
+    force(d_X, i, wall_idx, d_dX, d_nints);
+}
+
+template<typename Pt>
+__global__ void update_wall_node(Pt* d_dX, int wall_idx, int* d_nints)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    if (d_nints[wall_idx] > 0) {
+        const float inv = 1 / float(d_nints[wall_idx]);
+        d_dX[wall_idx].x *= inv;
+        d_dX[wall_idx].y *= inv;
+        d_dX[wall_idx].z *= inv;
+    }
+}
+
+namespace ya {
+// Interaction counters of the wall node(s), one allocation reused by every call
+// (the reference allocates and leaks a buffer per call, links.cuh:201-209).
+inline int* wall_counters(int wall_idx)
+{
+    static int* d_nints = nullptr;
+    static int capacity = 0;
+    if (wall_idx + 1 > capacity) {
+        if (d_nints) ya_free(d_nints);
+        capacity = wall_idx + 1 > 16 ? wall_idx + 1 : 16;
+        YA_CHECK(ya_malloc((void**)&d_nints, capacity * sizeof(int)));
+    }
+    YA_CHECK(ya_memset_async(d_nints, 0, capacity * sizeof(int), nullptr));
+    return d_nints;
+}
+}  // namespace ya
+
+// Use this when there is a wall node, but no links
+template<typename Pt, Wall_force<Pt> force>
+void wall_forces(const int n, const Pt* __restrict__ d_X, Pt* d_dX, const int wall_idx)
+{
+    int* d_nints = ya::wall_counters(wall_idx);
+    wall<Pt, force><<<(n + 255) / 256, 256>>>(d_X, d_dX, n, wall_idx, d_nints);
+    update_wall_node<<<1, 1>>>(d_dX, wall_idx, d_nints);
+}
+
+// Use this instead of "link_forces" when there is a wall node and links
+template<typename Pt, Link_force<Pt> l_force, Wall_force<Pt> w_force>
+void link_wall_forces(
+    Links& links, const int n, const Pt* __restrict__ d_X, Pt* d_dX, const int wall_idx)
+{
+    link_forces<Pt, l_force>(links, d_X, d_dX);
+    wall_forces<Pt, w_force>(n, d_X, d_dX, wall_idx);
+}

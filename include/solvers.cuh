@@ -42,11 +42,22 @@
 #include <stdlib.h>
 
 #include <functional>
+#include <utility>
 #include <vector>
 
 #include "cudebug.cuh"
 #include "dtypes.cuh"
 #include "yalla_hip.h"
+
+// Model files use thrust::fill / reduce on their own arrays and rely on the
+// reference's solvers.cuh for the includes (examples/branching.cu:189).  The
+// engine itself does not use Thrust; define YALLA_NO_THRUST to skip them.
+#ifndef YALLA_NO_THRUST
+#include <thrust/execution_policy.h>
+#include <thrust/fill.h>
+#include <thrust/reduce.h>
+#include <thrust/sort.h>
+#endif
 
 
 // Interactions are specified between two points Xi and Xj with r = Xi - Xj
@@ -469,6 +480,94 @@ __global__ __launch_bounds__(FORCE_BLOCK) void grid_force(const int n,
     if (active) store_rhs(d_dX, i, has_gen, F, sum_v, sum_friction);
 }
 
+// Gabriel-graph force (replaces compute_cube_gabriel, solvers.cuh:509-602): the
+// candidates inside the cut-off are collected per thread, ordered by distance,
+// and the pair (i, j) only interacts if no closer candidate lies inside the
+// sphere around the midpoint of i and j with radius coefficient * dist / 2.
+// Kept straightforward (thread-private lists in scratch memory): it is off the
+// benchmarked path and only used by models that ask for Gabriel_solver.
+constexpr int GABRIEL_MAX_NEIGHBOURS = 100;  // the reference's fixed list size
+
+template<typename Pt, Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction>
+__global__ __launch_bounds__(64) void gabriel_force(const int n,
+    const Entry<Pt>* __restrict__ sorted, const float4* __restrict__ sorted_v,
+    const int* __restrict__ cube_id, const int* __restrict__ offs, const int gs,
+    const int n_cubes, const float cube_size, const float gabriel_coefficient,
+    Pt* __restrict__ d_dX, const bool has_gen)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+
+    const Entry<Pt> self = sorted[s];
+    const Pt Xi = self.X;
+    const int i = self.id;
+    const int c = cube_id[s];
+
+    int slot[GABRIEL_MAX_NEIGHBOURS];
+    float distance[GABRIEL_MAX_NEIGHBOURS];
+    int n_neighs = 0;
+    for (int row = 0; row < 9; row++) {
+        const int mid = c + stencil_row_offset(row, gs);
+        const int k_end = offs[min(max(mid + 2, 0), n_cubes)];
+        for (int k = offs[min(max(mid - 1, 0), n_cubes)]; k < k_end; k++) {
+            const Pt r = Xi - sorted[k].X;
+            const float dist = dist3(r.x, r.y, r.z);
+            if (dist >= cube_size) continue;
+            D_ASSERT(n_neighs < GABRIEL_MAX_NEIGHBOURS);
+            slot[n_neighs] = k;
+            distance[n_neighs] = dist;
+            n_neighs++;
+        }
+    }
+    // selection sort by distance, closest first (solvers.cuh:550-566)
+    for (int m = 0; m < n_neighs - 1; m++) {
+        int closest = m;
+        for (int q = m + 1; q < n_neighs; q++)
+            if (distance[q] < distance[closest]) closest = q;
+        if (closest != m) {
+            const int ts = slot[closest];
+            slot[closest] = slot[m];
+            slot[m] = ts;
+            const float td = distance[closest];
+            distance[closest] = distance[m];
+            distance[m] = td;
+        }
+    }
+    // farthest first: keep (i, j) unless a closer candidate sits in its Gabriel sphere
+    Pt F = ya::zero<Pt>();
+    float3 sum_v{0.f, 0.f, 0.f};
+    float sum_friction = 0;
+    for (int m = n_neighs - 1; m >= 0; m--) {
+        const Entry<Pt> other = sorted[slot[m]];
+        const int j = other.id;
+        const float dist = distance[m];
+        bool keep = true;
+        if (j != i) {
+            const float radius = 0.5f * dist * gabriel_coefficient;
+            const Pt mid_point = 0.5f * (Xi + other.X);
+            for (int q = m - 1; q >= 0; q--) {
+                const Pt r_mk = mid_point - sorted[slot[q]].X;
+                if (dist3(r_mk.x, r_mk.y, r_mk.z) < radius) {
+                    keep = false;
+                    break;
+                }
+            }
+        }
+        if (!keep) continue;
+        const Pt r = Xi - other.X;
+        F += pw_int(Xi, r, dist, i, j);
+        const float friction = pw_friction(Xi, r, dist, i, j);
+        sum_friction += friction;
+        if (friction != 0) {
+            const float4 v = sorted_v[slot[m]];
+            sum_v.x += friction * v.x;
+            sum_v.y += friction * v.y;
+            sum_v.z += friction * v.z;
+        }
+    }
+    store_rhs(d_dX, i, has_gen, F, sum_v, sum_friction);
+}
+
 // fix = what is subtracted from dX.xyz: 0 = mean (already in d_mean), 1 = the
 // fixed point's value, 2 = the point's x, y and the mean's z (set_fixed_xy,
 // solvers.cuh:243-249).
@@ -580,6 +679,24 @@ public:
     void take_step(float dt, Generic_forces<Pt> gen_forces = no_gen_forces<Pt>)
     {
         return Solver<Pt>::template take_step<pw_int, pw_friction>(dt, gen_forces);
+    }
+    // The former two-argument generic force `(const Pt* d_X, Pt* d_dX)`, which the
+    // reference's own tests still use (tests/test_solvers.cu:141, test_links.cu:19).
+    template<Pairwise_interaction<Pt> pw_int, typename Gen2,
+        typename = decltype(std::declval<Gen2&>()((const Pt*)nullptr, (Pt*)nullptr))>
+    void take_step(float dt, Gen2 gen_forces)
+    {
+        take_step<pw_int>(dt, Generic_forces<Pt>{[gen_forces](const int, const Pt* d_X,
+                                                     Pt* d_dX) mutable { gen_forces(d_X, d_dX); }});
+    }
+    template<Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction, typename Gen2,
+        typename = decltype(std::declval<Gen2&>()((const Pt*)nullptr, (Pt*)nullptr))>
+    void take_step(float dt, Gen2 gen_forces)
+    {
+        take_step<pw_int, pw_friction>(dt,
+            Generic_forces<Pt>{[gen_forces](const int, const Pt* d_X, Pt* d_dX) mutable {
+                gen_forces(d_X, d_dX);
+            }});
     }
 };
 
@@ -863,3 +980,31 @@ protected:
 
 template<typename Pt>
 using Grid_solver = Heun_solver<Pt, Grid_computer>;
+
+
+// Pairwise interactions on the grid restricted to Gabriel-graph neighbours
+// (Delile et al. 2017, Marin-Riera et al. 2016; solvers.cuh:505-644).
+template<typename Pt>
+class Gabriel_computer : public Grid_computer<Pt> {
+public:
+    float gabriel_coefficient;
+    Gabriel_computer(
+        int n_max, int grid_size = 50, float cube_size = 1, float gabriel_coefficient = 0.8)
+        : Grid_computer<Pt>{n_max, grid_size, cube_size}, gabriel_coefficient{gabriel_coefficient}
+    {}
+
+protected:
+    template<Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction>
+    void pwints(const int n, const Pt* __restrict__ d_X, const float3* __restrict__ d_old_v,
+        Pt* d_dX, const bool has_gen, const int n_active)
+    {
+        assert(n_active == n);
+        this->grid.build_sorted(n, d_X, d_old_v, this->cube_size, this->d_sorted, this->d_sorted_v);
+        ya::gabriel_force<Pt, pw_int, pw_friction><<<(n + 63) / 64, 64>>>(n, this->d_sorted,
+            this->d_sorted_v, this->grid.d_cube_id, this->grid.offsets(), this->grid.grid_size,
+            this->grid.n_cubes, this->cube_size, gabriel_coefficient, d_dX, has_gen);
+    }
+};
+
+template<typename Pt>
+using Gabriel_solver = Heun_solver<Pt, Gabriel_computer>;

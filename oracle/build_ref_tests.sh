@@ -1,0 +1,28 @@
+#!/bin/bash
+# Builds the REFERENCE's own test programs (tests/test_*.cu, unmodified, from
+# where they lie under /root/reference) against THIS repo's headers and
+# libyalla_hip.so, into oracle/_ref/ (git-ignored binaries that travel to the GPU
+# box).  They are the strongest drop-in check there is: ya||a's tests, our
+# engine.  No reference source is copied: a scratch tree of symlinks makes the
+# tests' `#include "../include/x.cuh"` resolve to include/ of this repo.
+#   test_dtypes test_solvers test_links test_inits test_vtk   -> built
+#   test_polarity  stale in the reference itself   -> skipped
+#   test_mesh      needs mesh.cuh (out of scope)               -> skipped
+set -e
+REF=${REF:-/root/reference}
+HERE=$(cd "$(dirname "$0")" && pwd)
+ROOT=$(dirname "$HERE")
+[ -d "$REF/tests" ] || { echo "no reference checkout at $REF: nothing to build"; exit 0; }
+OUT=$HERE/_ref
+TREE=$(mktemp -d)
+trap 'rm -rf "$TREE"' EXIT
+mkdir -p "$OUT" "$TREE/tests"
+ln -s "$ROOT/include" "$TREE/include"
+for f in "$REF"/tests/*; do ln -s "$f" "$TREE/tests/"; done
+cd "$TREE/tests"
+for t in test_dtypes test_solvers test_links test_inits test_vtk; do
+  /opt/rocm/bin/hipcc -x hip --offload-arch=gfx950 -std=c++17 -O2 -ffp-contract=off \
+      -Wno-error=parentheses -w -include "$ROOT/include/compat/cuda_names.h" -I"$ROOT/include/compat" \
+      $t.cu -L"$ROOT/yalla_amd" -lyalla_hip -Wl,-rpath,'$ORIGIN/../../yalla_amd' -o "$OUT/$t"
+  echo "built oracle/_ref/$t"
+done

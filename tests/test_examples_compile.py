@@ -1,0 +1,56 @@
+"""The reference's model files (examples/*.cu), UNCHANGED, must compile against
+this repo's headers for gfx950 (north_star: "every examples/*.cu model compiles
+against it unchanged").  Runs only where the reference checkout exists (this
+container).  A scratch tree of symlinks makes `#include "../include/x.cuh"`
+resolve to this repo's include/; nothing is copied.
+
+19 of 23 compile.  Known exceptions, not chased this round:
+  polarization.cu             reference bug: passes a Po_cell where its own
+                              polarity.cuh wants a Polarity
+  intercalation_w_gradient.cu, model_features_sequential_addition.cu, teapot.cu
+                              need mesh.cuh (image-based set-up, out of scope)
+"""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference/examples"
+BASELINE_CONFIGS = ["springs", "sorting", "branching", "passive_growth"]
+OTHERS = ["apical_constriction", "bending", "epithelia_double_polarity", "epithelium", "gradient",
+          "growth_w_wall", "intercalation", "lineage_tracing", "migration", "random_walk",
+          "sorting_prot", "turing", "turing_w_noise", "wnt", "write_vtk_w_mask"]
+
+pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="no reference checkout here")
+
+
+@pytest.fixture(scope="module")
+def tree(tmp_path_factory):
+    base = tmp_path_factory.mktemp("compat")
+    (base / "examples").mkdir()
+    os.symlink(os.path.join(ROOT, "include"), base / "include")
+    for f in os.listdir(REF):
+        os.symlink(os.path.join(REF, f), base / "examples" / f)
+    return base
+
+
+def compile_model(tree, name):
+    cmd = ["/opt/rocm/bin/hipcc", "-x", "hip", "--offload-arch=gfx950", "-std=c++17", "-O1",
+           "-Wno-error=parentheses", "-w",
+           "-include", os.path.join(ROOT, "include", "compat", "cuda_names.h"),
+           "-I" + os.path.join(ROOT, "include", "compat"),
+           "-c", name + ".cu", "-o", str(tree / (name + ".o"))]
+    proc = subprocess.run(cmd, cwd=tree / "examples", capture_output=True, text=True, timeout=900)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+
+
+@pytest.mark.parametrize("name", BASELINE_CONFIGS)
+def test_baseline_config_examples_compile_unchanged(tree, name):
+    compile_model(tree, name)
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("name", OTHERS)
+def test_other_examples_compile_unchanged(tree, name):
+    compile_model(tree, name)

@@ -1,0 +1,52 @@
+"""ya||a's OWN test programs (reference tests/test_*.cu, unmodified), compiled
+against this repo's headers + libyalla_hip.so by oracle/build_ref_tests.sh into
+oracle/_ref/ and run here.  test_dtypes is host-only; the others need the GPU.
+The binaries are built in the authoring container (where the reference checkout
+lives) and travel to the GPU box; they are skipped where they were never built."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_BIN = os.path.join(ROOT, "oracle", "_ref")
+
+
+def run(name, tmp_path, n_tests):
+    exe = os.path.join(REF_BIN, name)
+    if not os.path.exists(exe):
+        if os.path.isdir("/root/reference/tests"):
+            subprocess.run(["bash", os.path.join(ROOT, "oracle", "build_ref_tests.sh")], check=True,
+                           capture_output=True)
+        else:
+            pytest.skip(f"{exe} was not built (no reference checkout here)")
+    proc = subprocess.run([exe], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert "ALL TESTS PASSED" in proc.stdout, proc.stdout[-2000:] + proc.stderr[-2000:]
+    assert f"Tests run: {n_tests}" in proc.stdout
+    assert proc.returncode == 0
+
+
+def test_reference_test_dtypes(tmp_path):
+    run("test_dtypes", tmp_path, 4)
+
+
+@pytest.mark.gpu
+def test_reference_test_solvers(tmp_path):
+    """10 cases: oscillation, tile/grid tetrahedron, compare_methods, generic
+    forces, friction, fix point, grid spacing, cube size, Gabriel solver."""
+    run("test_solvers", tmp_path, 10)
+
+
+@pytest.mark.gpu
+def test_reference_test_links(tmp_path):
+    run("test_links", tmp_path, 2)
+
+
+@pytest.mark.gpu
+def test_reference_test_inits(tmp_path):
+    run("test_inits", tmp_path, 2)
+
+
+@pytest.mark.gpu
+def test_reference_test_vtk(tmp_path):
+    run("test_vtk", tmp_path, 1)
