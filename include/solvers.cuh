@@ -95,7 +95,10 @@ void no_gen_forces(const int n, const Pt* __restrict__ d_X, Pt* d_dX)
 
 namespace ya {
 
-constexpr int FORCE_BLOCK = 256;   // grid force: 4 wavefronts per workgroup
+#ifndef YA_FORCE_BLOCK
+#define YA_FORCE_BLOCK 256
+#endif
+constexpr int FORCE_BLOCK = YA_FORCE_BLOCK;  // grid force: cells (threads) per workgroup
 constexpr int TILE_BLOCK = 64;     // tile force: one wavefront per workgroup
 constexpr int TILE_POINTS = 256;   // points staged in LDS per tile
 constexpr int UPDATE_BLOCK = 256;
@@ -305,7 +308,7 @@ inline float cutoff_squared(float cube_size)
 template<typename Pt>
 struct Stage_cells {
 #ifndef YA_STAGE_CELLS
-#define YA_STAGE_CELLS 1024
+#define YA_STAGE_CELLS (3 * YA_FORCE_BLOCK + 256)
 #endif
     static constexpr int value =
         sizeof(Entry<Pt>) <= 16 ? YA_STAGE_CELLS : (sizeof(Entry<Pt>) <= 32 ? YA_STAGE_CELLS * 3 / 4 : YA_STAGE_CELLS / 2);
@@ -342,13 +345,16 @@ __global__ __launch_bounds__(FORCE_BLOCK) void grid_force(const int n,
     const int n_active)
 {
     constexpr int CAP = Stage_cells<Pt>::value;
-    __shared__ Entry<Pt> sh_e[CAP + 4];  // +4: phase 1 reads whole groups of four
+    __shared__ Entry<Pt> sh_e[CAP + 8];  // slack: phase 1 reads whole groups
     __shared__ float4 sh_v[CAP];
     __shared__ unsigned short sh_q[QUEUE_DEPTH * FORCE_BLOCK];
     // LDS (address space 3) FIFO pointers: 32-bit address arithmetic in the hot loops
     using Lds_u16 = __attribute__((address_space(3))) unsigned short;
     Lds_u16* const q_base = (Lds_u16*)sh_q + threadIdx.x;          // this lane's FIFO, stride 256
-    Lds_u16* const q_high = q_base + (QUEUE_DEPTH - 4) * FORCE_BLOCK;  // "nearly full" mark
+#ifndef YA_GROUP
+#define YA_GROUP 4
+#endif
+    Lds_u16* const q_high = q_base + (QUEUE_DEPTH - YA_GROUP) * FORCE_BLOCK;  // "nearly full" mark
 
     const int s0 = blockIdx.x * FORCE_BLOCK;
     const int s = s0 + threadIdx.x;
@@ -441,20 +447,23 @@ __global__ __launch_bounds__(FORCE_BLOCK) void grid_force(const int n,
             int t = max(k_begin[0] - wg_begin[0], chunk) - chunk;
             int b = min(k_end[0] - wg_begin[0], chunk + chunk_n) - chunk;
             while (true) {
-                while (t + 4 <= b && q_tail <= q_high) {
-                    float d2[4];
+#ifndef YA_GROUP
+#define YA_GROUP 4
+#endif
+                while (t + YA_GROUP <= b && q_tail <= q_high) {
+                    float d2[YA_GROUP];
 #pragma unroll
-                    for (int u = 0; u < 4; u++) d2[u] = dist2_to(t + u);
+                    for (int u = 0; u < YA_GROUP; u++) d2[u] = dist2_to(t + u);
 #pragma unroll
-                    for (int u = 0; u < 4; u++) {
+                    for (int u = 0; u < YA_GROUP; u++) {
                         if (d2[u] < cut2) {
                             *q_tail = (unsigned short)(t + u);
                             q_tail += FORCE_BLOCK;
                         }
                     }
-                    t += 4;
+                    t += YA_GROUP;
                 }
-                while (t < b && q_tail <= q_last && (t + 4 > b || q_tail > q_high)) {
+                while (t < b && q_tail <= q_last && (t + YA_GROUP > b || q_tail > q_high)) {
                     if (dist2_to(t) < cut2) {
                         *q_tail = (unsigned short)t;
                         q_tail += FORCE_BLOCK;

@@ -25,15 +25,15 @@ def reference_run(lib, n, gs, dist, seed, dt, steps, tree=False):
         return X0, s.positions()
 
 
-def slab_run(lib, X0, world, gs, dt, steps, device="cpu"):
+def slab_run(lib, X0, world, gs, dt, steps, device="cpu", migrate_every=1):
     bounds = slab_mod.slab_bounds(X0[:, 2], world)
     slabs = [slab_mod.Slab("springs_grid", X0, r, world, bounds, gs, lib=lib, device=device)
              for r in range(world)]
     comm = slab_mod.LocalComm()
     moved = 0
     owners0 = [set(s.own_cells()[0].tolist()) for s in slabs]
-    for _ in range(steps):
-        slab_mod.step(slabs, comm, dt)
+    for k in range(steps):
+        slab_mod.step(slabs, comm, dt, migrate=(k + 1) % migrate_every == 0 or k == steps - 1)
     X = np.zeros_like(X0)
     seen = np.zeros(len(X0), bool)
     for r, s in enumerate(slabs):
@@ -47,9 +47,9 @@ def slab_run(lib, X0, world, gs, dt, steps, device="cpu"):
     return X, moved
 
 
-def check(lib, n, world, steps, dt, device="cpu"):
+def check(lib, n, world, steps, dt, device="cpu", migrate_every=1):
     X0, Xref = reference_run(lib, n, 50, 0.5, 3, dt, steps)
-    X, moved = slab_run(lib, X0, world, 50, dt, steps, device)
+    X, moved = slab_run(lib, X0, world, 50, dt, steps, device, migrate_every)
     scale = np.abs(Xref).max()
     assert np.abs(X - Xref).max() <= 1e-5 * scale
     return moved
@@ -63,6 +63,12 @@ def test_slabs_match_undivided_system_oracle(oracle, world):
 def test_cells_migrate_between_slabs_oracle(oracle):
     moved = check(oracle, 3000, 4, 12, 0.004)
     assert moved > 0, "test too gentle: nothing crossed a slab face"
+
+
+def test_postponed_migration_oracle(oracle):
+    """Migrating every 4th step only: strays stay inside the ghost margin."""
+    moved = check(oracle, 3000, 3, 12, 0.002, migrate_every=4)
+    assert moved >= 0
 
 
 def test_two_gloo_ranks_match_undivided_system(oracle, tmp_path):

@@ -257,8 +257,12 @@ class DistComm:
         self.dist.all_reduce(s.sum.as_tensor().view(torch.float32))
 
 
-def step(slabs, comm, dt):
-    """One take_step of the decomposed system (both Heun stages + migration)."""
+def step(slabs, comm, dt, migrate=True):
+    """One take_step of the decomposed system (both Heun stages, then migration).
+    `migrate=False` postpones the hand-over of cells that left their slab: legal
+    while no cell has strayed further than the halo margin (0.25 cube_size by
+    default) beyond its slab since the last migration -- the ghost layer covers
+    it; callers that skip must migrate every few steps."""
     for stage in (1, 2):
         for s in slabs:
             s.pack_halo(stage)
@@ -270,6 +274,8 @@ def step(slabs, comm, dt):
         comm.allreduce(slabs)
         for s in slabs:
             s.stage_update(stage, dt)
+    if not migrate:
+        return
     for s in slabs:
         s.migrate_pack()
     comm.exchange(slabs, "mig")
