@@ -3,6 +3,7 @@ inside the functor, bending_force between epithelial cells."""
 import numpy as np
 import pytest
 
+import branching_case
 import growth_case
 
 
@@ -56,5 +57,53 @@ def test_growth_device_matches_oracle(oracle, device, solver):
         sd.set_old_v(so.old_v())
         n_before = n_o
     assert n_before > 200, "nothing divided"
+    so.close()
+    sd.close()
+
+
+def test_branching_on_oracle(oracle):
+    s, nbs = branching_case.setup(oracle)
+    t = s.get_prop("type", 500)
+    assert 0 < t.sum() < 500
+    n = [s.get_d_n()]
+    for _ in range(15):
+        s.take_step(0.2)
+        n.append(s.get_d_n())
+    assert n[-1] > 500 and n == sorted(n)
+    X = s.positions()
+    assert np.isfinite(X).all()
+    tt = s.get_prop("type", n[-1])
+    assert (X[tt == 0, 5] == 0).all(), "u only lives on the epithelium"
+    assert (X[tt == 1, 6] != 0).any()
+    s.close()
+
+
+@pytest.mark.gpu
+def test_branching_device_matches_oracle_lockstep(oracle, device):
+    """Config 3: 7-float points, atomics inside the functor, division before the
+    step.  Identical cell counts / types / counters, positions and morphogens to
+    1e-5 relative per step (libm differs between ocml and glibc)."""
+    so, nbs_o = branching_case.setup(oracle)
+    sd, nbs_d = branching_case.setup(device)
+    assert np.array_equal(nbs_o, nbs_d)
+    assert np.array_equal(so.get_prop("type", 500), sd.get_prop("type", 500))
+    grown = False
+    for step in range(12):
+        so.take_step(0.2)
+        sd.take_step(0.2)
+        n_o, n_d = so.get_d_n(), sd.get_d_n()
+        assert n_o == n_d, f"cell counts differ at step {step}"
+        grown = grown or n_o > 500
+        Xo, Xd = so.positions(), sd.positions()
+        for cols in (slice(0, 3), slice(3, 5), slice(5, 7)):
+            scale = max(np.abs(Xo[:, cols]).max(), 1e-3)
+            assert np.abs(Xo[:, cols] - Xd[:, cols]).max() <= 1e-5 * scale, (step, cols)
+        for name in ("type", "mes_nbs", "epi_nbs"):
+            assert np.array_equal(so.get_prop(name, n_o), sd.get_prop(name, n_d)), (name, step)
+        sd.h_X[:] = so.h_X
+        sd.h_n = n_o
+        sd.copy_to_device()
+        sd.set_old_v(so.old_v())
+    assert grown
     so.close()
     sd.close()

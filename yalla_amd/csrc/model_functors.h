@@ -21,6 +21,9 @@
     } while (0)
 #endif
 
+// examples/branching.cu:57 (MAKE_PT must sit at global scope)
+MAKE_PT(Cell, theta, phi, u, v);
+
 namespace models {
 
 // --- springs: examples/springs.cu:7-21 (all-to-all springs of rest length L_0;
@@ -165,55 +168,165 @@ __device__ __host__ inline float hash_uniform(unsigned seed, unsigned step, unsi
     return ((x >> 8) + 1) * (1.0f / 16777216.0f);
 }
 
-// Does cell i divide this step?  (passive_growth.cu:67-78)
-__device__ __host__ inline bool pg_divides(float rate, unsigned seed, unsigned step, int i,
-    const int* type, const int* mes_nbs, const int* epi_nbs)
+// Division rules.  A rule says whether cell i of the n current cells divides
+// this step and how daughter `d` is made from mother i; `rate` and `mean_dist`
+// are model parameters.  Passive growth: examples/passive_growth.cu:60-91.
+struct Passive_growth_rule {
+    using Pt = Po_cell;
+    __device__ __host__ static bool divides(float rate, unsigned seed, unsigned step, int i, int n,
+        const Pt* X, const int* type, const int* mes_nbs, const int* epi_nbs)
+    {
+        if (type[i] == mesenchyme) return !(hash_uniform(seed, step, i, 0) > rate);
+        return !(epi_nbs[i] > mes_nbs[i]);
+    }
+    __device__ __host__ static void divide(double mean_dist, unsigned seed, unsigned step, int i,
+        int d, Pt* X, float3* old_v, int* type, int* mes_nbs, int* epi_nbs)
+    {
+        auto theta = acosf(2. * hash_uniform(seed, step, i, 1) - 1);
+        auto phi = hash_uniform(seed, step, i, 2) * 2 * M_PI;
+        X[d].x = X[i].x + mean_dist / 4 * sinf(theta) * cosf(phi);
+        X[d].y = X[i].y + mean_dist / 4 * sinf(theta) * sinf(phi);
+        X[d].z = X[i].z + mean_dist / 4 * cosf(theta);
+        X[d].theta = X[i].theta;
+        X[d].phi = X[i].phi;
+        type[d] = type[i];
+        mes_nbs[d] = 0;
+        epi_nbs[d] = 0;
+        old_v[d] = old_v[i];
+    }
+};
+
+// --- branching: examples/branching.cu:14-170 (Turing pattern of two morphogens
+// u, v on the epithelium drives mesenchymal proliferation; Cell = Po_cell + u, v;
+// neighbour counters by atomicAdd).  Lineage tracing (:155-169) is bookkeeping
+// outside the step path and is left out. ------------------------------------------
+__device__ inline Cell epi_turing_mes_noturing(Cell Xi, Cell r, float dist, int i, int j)
 {
-    if (type[i] == mesenchyme) return !(hash_uniform(seed, step, i, 0) > rate);
-    return !(epi_nbs[i] > mes_nbs[i]);
+    const auto r_max = 1.0f;
+    const auto lambda = 0.0075;
+    const auto D_u = 0.001;
+    const auto D_v = 0.2;
+    const auto f_v = 1.0;
+    const auto f_u = 80.0;
+    const auto g_u = 80.0;
+    const auto m_u = 0.25;  // degradation rates
+    const auto m_v = 0.75;
+    const auto s_u = 0.05;
+    Cell dF{0};
+
+    // Meinhardt kinetics in the self-interaction
+    if (i == j) {
+        if (d_type[i] == epithelium) {
+            dF.u = lambda * ((f_u * Xi.u * Xi.u) / (1 + f_v * Xi.v) - m_u * Xi.u + s_u);
+            dF.v = lambda * (g_u * Xi.u * Xi.u - m_v * Xi.v);
+            // Prevent negative values
+            if (-dF.u > Xi.u) dF.u = 0.0f;
+            if (-dF.v > Xi.v) dF.v = 0.0f;
+        }
+        return dF;
+    }
+
+    if (dist > r_max) return dF;
+
+    float F;
+    if (d_type[i] == d_type[j]) {
+        F = fmaxf(0.7 - dist, 0) * 2 - fmaxf(dist - 0.8, 0);
+    } else {
+        F = fmaxf(0.8 - dist, 0) * 2 - fmaxf(dist - 0.9, 0);
+    }
+    dF.x = r.x * F / dist;
+    dF.y = r.y * F / dist;
+    dF.z = r.z * F / dist;
+
+    // Diffusion
+    if (d_type[i] == epithelium && d_type[j] == epithelium) {
+        dF.u = -D_u * r.u;
+        dF.v = -D_v * r.v;
+        if (-dF.u > Xi.u) dF.u = 0.0f;
+        if (-dF.v > Xi.v) dF.v = 0.0f;
+        dF += bending_force(Xi, r, dist) * 0.2;
+    } else {
+        dF.v = -D_v * r.v;  // Diffuses into mesenchyme to induce proliferation
+    }
+
+    if (d_type[j] == epithelium)
+        atomicAdd(&d_epi_nbs[i], 1);
+    else
+        atomicAdd(&d_mes_nbs[i], 1);
+
+    return dF;
 }
 
-// Daughter n of mother i (passive_growth.cu:80-90).
-__device__ __host__ inline void pg_divide(double mean_dist, unsigned seed, unsigned step, int i,
-    int n, Po_cell* X, float3* old_v, int* type, int* mes_nbs, int* epi_nbs)
-{
-    auto theta = acosf(2. * hash_uniform(seed, step, i, 1) - 1);
-    auto phi = hash_uniform(seed, step, i, 2) * 2 * M_PI;
-    X[n].x = X[i].x + mean_dist / 4 * sinf(theta) * cosf(phi);
-    X[n].y = X[i].y + mean_dist / 4 * sinf(theta) * sinf(phi);
-    X[n].z = X[i].z + mean_dist / 4 * cosf(theta);
-    X[n].theta = X[i].theta;
-    X[n].phi = X[i].phi;
-    type[n] = type[i];
-    mes_nbs[n] = 0;
-    epi_nbs[n] = 0;
-    old_v[n] = old_v[i];
-}
+struct Branching_rule {  // examples/branching.cu:113-153
+    using Pt = Cell;
+    __device__ __host__ static bool divides(float, unsigned seed, unsigned step, int i, int n,
+        const Pt* X, const int* type, const int* mes_nbs, const int* epi_nbs)
+    {
+        const auto epi_proliferation_rate = 0.2;
+        const auto mes_proliferation_rate = 0.1;
+        const auto prolif_threshold = 1150.0f;
+        if (i >= n * (1 - epi_proliferation_rate)) return false;
+        const auto rnd = hash_uniform(seed, step, i, 0);
+        if (type[i] == mesenchyme) {
+            if (X[i].v < prolif_threshold) return false;
+            if (rnd > mes_proliferation_rate) return false;
+        } else {
+            if (epi_nbs[i] > 5) return false;
+            if (mes_nbs[i] <= 0) return false;
+            if (rnd > epi_proliferation_rate) return false;
+        }
+        return true;
+    }
+    __device__ __host__ static void divide(double mean_dist, unsigned seed, unsigned step, int i,
+        int d, Pt* X, float3* old_v, int* type, int* mes_nbs, int* epi_nbs)
+    {
+        const float mean_distance = mean_dist;
+        auto theta = acosf(2. * hash_uniform(seed, step, i, 1) - 1);
+        auto phi = hash_uniform(seed, step, i, 2) * 2 * M_PI;
+        X[d].x = X[i].x + mean_distance / 4 * sinf(theta) * cosf(phi);
+        X[d].y = X[i].y + mean_distance / 4 * sinf(theta) * sinf(phi);
+        X[d].u = X[i].u / 2;
+        X[d].z = X[i].z + mean_distance / 4 * cosf(theta);
+        X[i].u = X[i].u / 2;
+        X[d].v = X[i].v / 2;
+        X[i].v = X[i].v / 2;
+        X[d].theta = X[i].theta;
+        X[d].phi = X[i].phi;
+        type[d] = type[i];
+        old_v[d] = old_v[i];
+    }
+};
 
-// proliferate (passive_growth.cu:60-91), made reproducible: mothers are the cells
-// i < n that pg_divides() selects; daughters are appended in ascending mother
-// order (the example appends in atomicAdd arrival order).
+// proliferate, made reproducible: mothers are the cells i < n that the rule
+// selects; daughters are appended in ascending mother order (the examples append
+// in atomicAdd arrival order).
 #ifdef YA_ORACLE
-inline void pg_proliferate(float rate, double mean_dist, unsigned seed, unsigned step, int n,
-    Po_cell* X, float3* old_v, int* d_n, int* type, int* mes_nbs, int* epi_nbs, int*, int n_max)
+template<typename Rule>
+inline void proliferate(float rate, double mean_dist, unsigned seed, unsigned step, int n,
+    typename Rule::Pt* X, float3* old_v, int* d_n, int* type, int* mes_nbs, int* epi_nbs, int*,
+    int n_max)
 {
+    std::vector<char> mother(n);
+    for (int i = 0; i < n; i++)
+        mother[i] = Rule::divides(rate, seed, step, i, n, X, type, mes_nbs, epi_nbs);
     int n_new = n;
     for (int i = 0; i < n; i++) {
-        if (!pg_divides(rate, seed, step, i, type, mes_nbs, epi_nbs)) continue;
+        if (!mother[i]) continue;
         assert(n_new < n_max);
-        pg_divide(mean_dist, seed, step, i, n_new++, X, old_v, type, mes_nbs, epi_nbs);
+        Rule::divide(mean_dist, seed, step, i, n_new++, X, old_v, type, mes_nbs, epi_nbs);
     }
     *d_n = n_new;
 }
 #else
-__global__ void pg_flag(float rate, unsigned seed, unsigned step, int n, const int* type,
-    const int* mes_nbs, const int* epi_nbs, int* flag)
+template<typename Rule>
+__global__ void k_mothers(float rate, unsigned seed, unsigned step, int n,
+    const typename Rule::Pt* X, const int* type, const int* mes_nbs, const int* epi_nbs, int* flag)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) flag[i] = pg_divides(rate, seed, step, i, type, mes_nbs, epi_nbs);
+    if (i < n) flag[i] = Rule::divides(rate, seed, step, i, n, X, type, mes_nbs, epi_nbs);
 }
 // exclusive prefix of the flags by ONE workgroup (model-side helper, not a hot path)
-__global__ __launch_bounds__(1024) void pg_scan(int n, int* flag_to_offset, int* d_n, int n_max)
+__global__ __launch_bounds__(1024) void k_daughter_slots(int n, int* flag_to_offset, int* d_n, int n_max)
 {
     __shared__ int sh[1024];
     __shared__ int carry;
@@ -241,21 +354,24 @@ __global__ __launch_bounds__(1024) void pg_scan(int n, int* flag_to_offset, int*
         *d_n = n + carry;
     }
 }
-__global__ void pg_daughters(double mean_dist, unsigned seed, unsigned step, int n, const int* offset,
-    Po_cell* X, float3* old_v, int* type, int* mes_nbs, int* epi_nbs)
+template<typename Rule>
+__global__ void k_daughters(double mean_dist, unsigned seed, unsigned step, int n, const int* offset,
+    typename Rule::Pt* X, float3* old_v, int* type, int* mes_nbs, int* epi_nbs)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n || offset[i] < 0) return;
-    pg_divide(mean_dist, seed, step, i, n + offset[i], X, old_v, type, mes_nbs, epi_nbs);
+    Rule::divide(mean_dist, seed, step, i, n + offset[i], X, old_v, type, mes_nbs, epi_nbs);
 }
-inline void pg_proliferate(float rate, double mean_dist, unsigned seed, unsigned step, int n,
-    Po_cell* X, float3* old_v, int* d_n, int* type, int* mes_nbs, int* epi_nbs, int* scratch,
-    int n_max)
+template<typename Rule>
+inline void proliferate(float rate, double mean_dist, unsigned seed, unsigned step, int n,
+    typename Rule::Pt* X, float3* old_v, int* d_n, int* type, int* mes_nbs, int* epi_nbs,
+    int* scratch, int n_max)
 {
     const int blocks = (n + 255) / 256;
-    pg_flag<<<blocks, 256>>>(rate, seed, step, n, type, mes_nbs, epi_nbs, scratch);
-    pg_scan<<<1, 1024>>>(n, scratch, d_n, n_max);
-    pg_daughters<<<blocks, 256>>>(mean_dist, seed, step, n, scratch, X, old_v, type, mes_nbs, epi_nbs);
+    k_mothers<Rule><<<blocks, 256>>>(rate, seed, step, n, X, type, mes_nbs, epi_nbs, scratch);
+    k_daughter_slots<<<1, 1024>>>(n, scratch, d_n, n_max);
+    k_daughters<Rule><<<blocks, 256>>>(
+        mean_dist, seed, step, n, scratch, X, old_v, type, mes_nbs, epi_nbs);
 }
 #endif
 
