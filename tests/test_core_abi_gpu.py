@@ -1,0 +1,174 @@
+"""Direct calls into libyalla_hip.so (include/yalla_hip.h) on the GPU: grid build
+against a numpy restatement (bit-exact), ordered selection, row gather, the
+deterministic reduction, status flag."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from yalla_amd import _ffi
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    lib = C.CDLL(_ffi.CORE_LIB, mode=C.RTLD_LOCAL)
+    vp, sz, i32, f32 = C.c_void_p, C.c_size_t, C.c_int, C.c_float
+    lib.ya_malloc.argtypes = [C.POINTER(vp), sz]
+    lib.ya_free.argtypes = [vp]
+    lib.ya_memcpy_h2d.argtypes = [vp, vp, sz]
+    lib.ya_memcpy_d2h.argtypes = [vp, vp, sz]
+    lib.ya_grid_create.argtypes = [i32, i32, C.POINTER(vp)]
+    lib.ya_grid_destroy.argtypes = [vp]
+    lib.ya_grid_arrays.argtypes = [vp] + [C.POINTER(vp)] * 4
+    lib.ya_grid_offsets.argtypes = [vp, C.POINTER(vp)]
+    lib.ya_grid_build.argtypes = [vp, vp, sz, i32, f32, vp]
+    lib.ya_grid_status.argtypes = [vp, C.POINTER(i32), i32]
+    lib.ya_select_z.argtypes = [vp, sz, i32, f32, f32, vp, vp, vp, vp]
+    lib.ya_select_workspace_bytes.restype = sz
+    lib.ya_select_workspace_bytes.argtypes = [i32]
+    lib.ya_gather_rows.argtypes = [vp, sz, vp, vp, i32, vp, vp]
+    lib.ya_reduce_mean.argtypes = [vp, i32, i32, vp, vp, vp]
+    lib.ya_reduce_workspace_bytes.restype = sz
+    lib.ya_reduce_workspace_bytes.argtypes = [i32]
+    lib.ya_device_synchronize.argtypes = []
+    return lib
+
+
+class Dev:
+    def __init__(self, hip, array=None, nbytes=None):
+        self.hip = hip
+        self.p = C.c_void_p()
+        nbytes = array.nbytes if array is not None else nbytes
+        assert hip.ya_malloc(C.byref(self.p), max(nbytes, 4)) == 0
+        if array is not None:
+            a = np.ascontiguousarray(array)
+            assert hip.ya_memcpy_h2d(self.p, a.ctypes.data, a.nbytes) == 0
+
+    def get(self, dtype, count):
+        out = np.empty(count, dtype)
+        assert self.hip.ya_memcpy_d2h(out.ctypes.data, self.p, out.nbytes) == 0
+        return out
+
+    def __del__(self):
+        self.hip.ya_free(self.p)
+
+
+def numpy_grid(X, cs, gs):
+    """solvers.cuh:349-378 in numpy, float32 arithmetic in the reference's order."""
+    f = np.float32
+    half = f(gs // 2)
+    fx = np.floor(X[:, 0] / f(cs)) + half
+    fy = (np.floor(X[:, 1] / f(cs)) + half) * f(gs)
+    fz = ((np.floor(X[:, 2] / f(cs)) + half) * f(gs)) * f(gs)
+    ids = ((fx + fy) + fz).astype(np.int32)
+    order = np.argsort(ids, kind="stable").astype(np.int32)
+    sorted_ids = ids[order]
+    start = np.full(gs ** 3, -1, np.int32)
+    end = np.full(gs ** 3, -2, np.int32)
+    first = np.r_[True, sorted_ids[1:] != sorted_ids[:-1]]
+    last = np.r_[sorted_ids[1:] != sorted_ids[:-1], True]
+    start[sorted_ids[first]] = np.nonzero(first)[0]
+    end[sorted_ids[last]] = np.nonzero(last)[0]
+    return sorted_ids, order, start, end
+
+
+@pytest.mark.parametrize("n,stride_f,gs,cs", [(1, 3, 8, 1.0), (1000, 3, 20, 1.0), (50000, 5, 40, 0.7),
+                                             (200000, 7, 64, 1.0)])
+def test_grid_build_is_bit_exact(hip, n, stride_f, gs, cs):
+    rng = np.random.default_rng(n)
+    X = np.zeros((n, stride_f), np.float32)
+    X[:, :3] = (rng.random((n, 3), dtype=np.float32) - 0.5) * np.float32((gs - 3) * cs)
+    X[:, 3:] = 7.0  # extra fields must be ignored
+    dX = Dev(hip, X)
+    g = C.c_void_p()
+    assert hip.ya_grid_create(n, gs, C.byref(g)) == 0
+    ptrs = [C.c_void_p() for _ in range(4)]
+    hip.ya_grid_arrays(g, *[C.byref(p) for p in ptrs])
+    offs = C.c_void_p()
+    hip.ya_grid_offsets(g, C.byref(offs))
+    for rebuild in range(3):  # later builds visit cells in the previous sorted order
+        assert hip.ya_grid_build(g, dX.p, stride_f * 4, n, cs, None) == 0
+        hip.ya_device_synchronize()
+        got = []
+        for p, count in zip(ptrs, (n, n, gs ** 3, gs ** 3)):
+            out = np.empty(count, np.int32)
+            hip.ya_memcpy_d2h(out.ctypes.data, p, out.nbytes)
+            got.append(out)
+        ref = numpy_grid(X, cs, gs)
+        for name, a, b in zip(("cube_id", "point_id", "cube_start", "cube_end"), ref, got):
+            assert np.array_equal(a, b), (name, rebuild)
+        o = np.empty(gs ** 3 + 1, np.int32)
+        hip.ya_memcpy_d2h(o.ctypes.data, offs, o.nbytes)
+        counts = np.bincount(ref[0], minlength=gs ** 3)
+        assert np.array_equal(o, np.r_[0, np.cumsum(counts)].astype(np.int32))
+    bits = C.c_int(-1)
+    assert hip.ya_grid_status(g, C.byref(bits), 0) == 0 and bits.value == 0
+    hip.ya_grid_destroy(g)
+
+
+def test_out_of_grid_is_flagged(hip):
+    X = np.array([[0, 0, 0], [0, 0, 100.0]], np.float32)  # linear id beyond gs^3
+    dX = Dev(hip, X)
+    g = C.c_void_p()
+    assert hip.ya_grid_create(2, 10, C.byref(g)) == 0
+    assert hip.ya_grid_build(g, dX.p, 12, 2, 1.0, None) == 0
+    bits = C.c_int(0)
+    assert hip.ya_grid_status(g, C.byref(bits), 1) == 0 and bits.value == 1
+    assert hip.ya_grid_status(g, C.byref(bits), 0) == 0 and bits.value == 0  # cleared
+    hip.ya_grid_destroy(g)
+
+
+@pytest.mark.parametrize("n", [0, 1, 2047, 2048, 2049, 100000])
+def test_select_and_gather_keep_order(hip, n):
+    rng = np.random.default_rng(5)
+    X = rng.random((max(n, 1), 4), dtype=np.float32)
+    dX = Dev(hip, X)
+    d_idx = Dev(hip, nbytes=4 * max(n, 1))
+    d_count = Dev(hip, nbytes=16)
+    d_ws = Dev(hip, nbytes=hip.ya_select_workspace_bytes(max(n, 1)))
+    assert hip.ya_select_z(dX.p, 16, n, 0.25, 0.6, d_idx.p, d_count.p, d_ws.p, None) == 0
+    ref = np.nonzero((X[:n, 2] >= np.float32(0.25)) & (X[:n, 2] < np.float32(0.6)))[0].astype(np.int32)
+    count = int(d_count.get(np.int32, 1)[0])
+    assert count == len(ref)
+    assert np.array_equal(d_idx.get(np.int32, max(n, 1))[:count], ref)
+    cap = max(count, 1)
+    d_out = Dev(hip, nbytes=16 * cap)
+    assert hip.ya_gather_rows(dX.p, 16, d_idx.p, d_count.p, cap, d_out.p, None) == 0
+    assert np.array_equal(d_out.get(np.float32, 4 * cap).reshape(cap, 4)[:count], X[ref])
+
+
+@pytest.mark.parametrize("n,nf", [(1, 3), (255, 3), (70000, 5), (300000, 7)])
+def test_reduce_mean_matches_its_documented_order(hip, n, nf):
+    rng = np.random.default_rng(1)
+    v = (rng.random((n, nf), dtype=np.float32) - 0.5).astype(np.float32)
+    dv = Dev(hip, v)
+    d_out = Dev(hip, nbytes=8 * nf)
+    d_ws = Dev(hip, nbytes=hip.ya_reduce_workspace_bytes(nf))
+    assert hip.ya_reduce_mean(dv.p, nf, n, d_out.p, d_ws.p, None) == 0
+    out = d_out.get(np.float32, 2 * nf)
+    # DESIGN.md "deterministic COM reduction", in numpy float32
+    B = min(max((n + 255) // 256, 1), 1024)
+    pad = np.zeros((B * 256 * ((n + B * 256 - 1) // (B * 256)), nf), np.float32)
+    pad[:n] = v
+    lanes = pad.reshape(-1, B, 256, nf)
+    acc = np.zeros((B, 256, nf), np.float32)
+    for chunk in lanes:
+        acc = acc + chunk
+    def fold(a):  # a: (..., 256, nf)
+        s = 128
+        while s >= 1:
+            a = a[..., :s, :] + a[..., s:2 * s, :]
+            s //= 2
+        return a[..., 0, :]
+    part = fold(acc)                       # (B, nf)
+    lanes2 = np.zeros((256 * ((B + 255) // 256), nf), np.float32)
+    lanes2[:B] = part
+    acc2 = np.zeros((256, nf), np.float32)
+    for chunk in lanes2.reshape(-1, 256, nf):
+        acc2 = acc2 + chunk
+    total = fold(acc2)
+    assert np.array_equal(out[nf:].view(np.uint32), total.view(np.uint32))
+    inv = np.float32(1.0 / np.float64(np.float32(n)))
+    assert np.array_equal(out[:nf].view(np.uint32), (total * inv).view(np.uint32))
