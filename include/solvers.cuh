@@ -111,9 +111,44 @@ struct alignas((sizeof(Pt) + 4) % 16 == 0 ? 16 : ((sizeof(Pt) + 4) % 8 == 0 ? 8 
     int id;
 };
 
+// Correctly rounded square root for x = 0 or x >= 2^-96 (every squared distance
+// between distinct binary32 positions of a model): the hardware estimate
+// (v_sqrt_f32, <= 1 ulp) moved down or up by one ulp according to the sign of the
+// exact residuals x - (s -+ 1ulp) * s, which is the core of the compiler's own
+// expansion of sqrtf without its rescaling of tiny arguments (10 fewer VALU
+// instructions per interacting pair).  Tiny non-zero arguments take the library
+// path.  Verified against sqrtf for EVERY binary32 argument by
+// tests/test_parity_gpu.py (ya::check_sqrt_all).
+__device__ __forceinline__ float exact_sqrt(float x)
+{
+    if (__builtin_expect(x < 0x1p-96f && x > 0.f, 0)) return sqrtf(x);
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float s_down = __int_as_float(__float_as_int(s) - 1);
+    const float s_up = __int_as_float(__float_as_int(s) + 1);
+    const float r_down = fmaf(-s_down, s, x);
+    const float r_up = fmaf(-s_up, s, x);
+    float out = r_down <= 0.f ? s_down : s;
+    out = r_up > 0.f ? s_up : out;
+    return out;
+}
+
 __device__ __forceinline__ float dist3(float x, float y, float z)
 {
-    return sqrtf(fmaf(z, z, fmaf(y, y, x * x)));
+    return exact_sqrt(fmaf(z, z, fmaf(y, y, x * x)));
+}
+
+// Test hook: counts the binary32 bit patterns in [first, last] for which
+// exact_sqrt differs from sqrtf (NaNs compare by class).
+__global__ void check_sqrt_all(unsigned first, unsigned last, unsigned long long* mismatches)
+{
+    unsigned long long bad = 0;
+    for (unsigned long long u = (unsigned long long)first + blockIdx.x * blockDim.x + threadIdx.x;
+         u <= last; u += (unsigned long long)gridDim.x * blockDim.x) {
+        const float x = __int_as_float((int)(unsigned)u);
+        const float a = exact_sqrt(x), b = sqrtf(x);
+        if (__float_as_int(a) != __float_as_int(b) && !(a != a && b != b)) bad++;
+    }
+    if (bad) atomicAdd(mismatches, bad);
 }
 
 // Optional HIP-event timing of the force-kernel launches (bench.py's roofline

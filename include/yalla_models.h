@@ -107,6 +107,11 @@ int ya_slab_migrate_unpack(ya_sim* sim, const void* d_buf_lo, const void* d_buf_
 int ya_slab_n_own(ya_sim* sim);
 int ya_slab_get_own(ya_sim* sim, float* X_host, int* global_ids_host);
 
+/* Device only (test hook): number of binary32 bit patterns in [first, last] for
+ * which the engine's correctly rounded square root (ya::exact_sqrt, used for every
+ * pair distance) differs from sqrtf.  Returns -1 on the oracle. */
+long ya_check_sqrt(unsigned first_bits, unsigned last_bits);
+
 /* Oracle only: 0 = serial COM sum, 1 = the engine's documented tree order.
  * Returns -1 on the device build. */
 int ya_sim_set_reduce_order(ya_sim* sim, int order);

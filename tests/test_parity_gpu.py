@@ -183,3 +183,11 @@ def test_growing_and_shrinking_n(oracle, device):
             out.append(snaps)
     for a, b in zip(*out):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_pair_distance_sqrt_is_correctly_rounded_for_every_float(device):
+    """ya::exact_sqrt (the engine's sqrt for pair distances) against sqrtf for ALL
+    non-negative binary32 bit patterns, zero, denormals and infinity included."""
+    assert device.ya_check_sqrt(0x00000000, 0x7F800000) == 0
+    # negative arguments and NaNs cannot arise from a sum of squares; still equal in class
+    assert device.ya_check_sqrt(0x7F800001, 0x7F800100) == 0
