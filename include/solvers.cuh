@@ -337,19 +337,19 @@ inline float cutoff_squared(float cube_size)
     return t;
 }
 
-// Cells staged in LDS at a time (entry + old_v = 32 B per float3 cell) and the
-// per-thread hit-queue depth; 1024 * 32 B + 40 * 256 * 2 B = 52 KiB per
-// workgroup, i.e. three workgroups (12 wavefronts) per CU.
+// Cells staged in LDS at a time (16 B per float3 cell) and the per-thread
+// hit-queue depth: 960 * 16 B + 48 * 256 * 2 B = 39 KiB per workgroup, i.e. four
+// workgroups (16 wavefronts) per CU.  Swept on MI355X.
 template<typename Pt>
 struct Stage_cells {
 #ifndef YA_STAGE_CELLS
-#define YA_STAGE_CELLS (3 * YA_FORCE_BLOCK + 256)
+#define YA_STAGE_CELLS (3 * YA_FORCE_BLOCK + 192)
 #endif
     static constexpr int value =
         sizeof(Entry<Pt>) <= 16 ? YA_STAGE_CELLS : (sizeof(Entry<Pt>) <= 32 ? YA_STAGE_CELLS * 3 / 4 : YA_STAGE_CELLS / 2);
 };
 #ifndef YA_QUEUE_DEPTH
-#define YA_QUEUE_DEPTH 40
+#define YA_QUEUE_DEPTH 48
 #endif
 constexpr int QUEUE_DEPTH = YA_QUEUE_DEPTH;
 
@@ -360,7 +360,7 @@ constexpr int QUEUE_DEPTH = YA_QUEUE_DEPTH;
 // are the sub-range [offs[c + off_r - 1], offs[c + off_r + 2]).  The nine rows are
 // handled as three planes (dz = 0, -1, +1: rows 0-2, 3-5, 6-8 of the reference's
 // d_nhood order).  Per plane the workgroup copies its three slot ranges into LDS
-// (coalesced 16-byte loads of {X, id} and old_v), then every thread
+// (coalesced 16-byte loads of {X, id}), then every thread
 //
 //   phase 1  walks its candidates in the reference's order testing d2 < cut2
 //            only, and appends the LDS index of each hit (~15 % of the 27-cube
@@ -381,7 +381,6 @@ __global__ __launch_bounds__(FORCE_BLOCK) void grid_force(const int n,
 {
     constexpr int CAP = Stage_cells<Pt>::value;
     __shared__ Entry<Pt> sh_e[CAP + 8];  // slack: phase 1 reads whole groups
-    __shared__ float4 sh_v[CAP];
     __shared__ unsigned short sh_q[QUEUE_DEPTH * FORCE_BLOCK];
     // LDS (address space 3) FIFO pointers: 32-bit address arithmetic in the hot loops
     using Lds_u16 = __attribute__((address_space(3))) unsigned short;
@@ -413,6 +412,11 @@ __global__ __launch_bounds__(FORCE_BLOCK) void grid_force(const int n,
     Lds_u16* q_tail = q_base;
     asm volatile("" : "+v"(q_tail));
 
+    // LDS index of a staged cell -> its slot in the sorted arrays (set per chunk):
+    // old_v of an interacting neighbour is read from global memory (L1/L2 hits, the
+    // neighbours of a workgroup are a few contiguous slot ranges) rather than staged,
+    // which keeps the workgroup at 40 KiB of LDS = four workgroups per CU.
+    int slot_shift0 = 0, slot_shift1 = 0, slot_shift2 = 0, slot_v1 = 0, slot_v2 = 0;
     // Phase 2: drain this lane's FIFO (wavefront-wide loop, one code site).
     auto drain = [&]() {
         const int count = (int)(q_tail - q_base) / FORCE_BLOCK;
@@ -423,7 +427,8 @@ __global__ __launch_bounds__(FORCE_BLOCK) void grid_force(const int n,
             const int t = t_next;
             t_next = q_base[min(q + 1, QUEUE_DEPTH - 1) * FORCE_BLOCK];
             const Entry<Pt> other = sh_e[t];
-            const float4 v = sh_v[t];
+            const float4 v =
+                sorted_v[t + (t >= slot_v2 ? slot_shift2 : (t >= slot_v1 ? slot_shift1 : slot_shift0))];
             Pt r = Xi - other.X;
             float dist = dist3(r.x, r.y, r.z);
             const int j = other.id;
@@ -468,9 +473,13 @@ __global__ __launch_bounds__(FORCE_BLOCK) void grid_force(const int n,
                 const int shift = v >= v0[2] ? wg_begin[2] - v0[2]
                                              : (v >= v0[1] ? wg_begin[1] - v0[1] : wg_begin[0]);
                 sh_e[t] = sorted[v + shift];
-                sh_v[t] = sorted_v[v + shift];
             }
             __syncthreads();
+            slot_shift0 = wg_begin[0] + chunk;
+            slot_shift1 = wg_begin[1] - v0[1] + chunk;
+            slot_shift2 = wg_begin[2] - v0[2] + chunk;
+            slot_v1 = v0[1] - chunk;
+            slot_v2 = v0[2] - chunk;
 
             // One wavefront-uniform loop over the plane's rows.  Phase 1: each lane
             // walks its candidates of the current row, four per trip (their LDS reads
