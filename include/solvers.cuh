@@ -337,19 +337,29 @@ inline float cutoff_squared(float cube_size)
     return t;
 }
 
+template<typename Pt>
+__device__ __forceinline__ float dist2(const Pt& a, const Pt& b)
+{
+    const float dx = a.x - b.x;
+    const float dy = a.y - b.y;
+    const float dz = a.z - b.z;
+    return fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+}
+
 // Cells staged in LDS at a time (16 B per float3 cell) and the per-thread
-// hit-queue depth: 960 * 16 B + 48 * 256 * 2 B = 39 KiB per workgroup, i.e. four
-// workgroups (16 wavefronts) per CU.  Swept on MI355X.
+// hit-queue depth (one byte per queued hit): 928 * 16 B + 44 * 256 B = 26 KiB per
+// workgroup, i.e. six workgroups (24 wavefronts) per CU.  Swept on MI355X
+// (DESIGN.md §6): occupancy, not instruction count, is what limits this kernel.
 template<typename Pt>
 struct Stage_cells {
 #ifndef YA_STAGE_CELLS
-#define YA_STAGE_CELLS (3 * YA_FORCE_BLOCK + 192)
+#define YA_STAGE_CELLS (3 * YA_FORCE_BLOCK + 160)
 #endif
     static constexpr int value =
         sizeof(Entry<Pt>) <= 16 ? YA_STAGE_CELLS : (sizeof(Entry<Pt>) <= 32 ? YA_STAGE_CELLS * 3 / 4 : YA_STAGE_CELLS / 2);
 };
 #ifndef YA_QUEUE_DEPTH
-#define YA_QUEUE_DEPTH 48
+#define YA_QUEUE_DEPTH 44
 #endif
 constexpr int QUEUE_DEPTH = YA_QUEUE_DEPTH;
 
@@ -381,9 +391,11 @@ __global__ __launch_bounds__(FORCE_BLOCK) void grid_force(const int n,
 {
     constexpr int CAP = Stage_cells<Pt>::value;
     __shared__ Entry<Pt> sh_e[CAP + 8];  // slack: phase 1 reads whole groups
-    __shared__ unsigned short sh_q[QUEUE_DEPTH * FORCE_BLOCK];
+    // One byte per queued hit: (row of the plane) << 6 | offset of the candidate from
+    // the lane's anchor in that row (0..63).
+    __shared__ unsigned char sh_q[QUEUE_DEPTH * FORCE_BLOCK];
     // LDS (address space 3) FIFO pointers: 32-bit address arithmetic in the hot loops
-    using Lds_u16 = __attribute__((address_space(3))) unsigned short;
+    using Lds_u16 = __attribute__((address_space(3))) unsigned char;
     Lds_u16* const q_base = (Lds_u16*)sh_q + threadIdx.x;          // this lane's FIFO, stride 256
 #ifndef YA_GROUP
 #define YA_GROUP 4
@@ -417,37 +429,7 @@ __global__ __launch_bounds__(FORCE_BLOCK) void grid_force(const int n,
     // neighbours of a workgroup are a few contiguous slot ranges) rather than staged,
     // which keeps the workgroup at 40 KiB of LDS = four workgroups per CU.
     int slot_shift0 = 0, slot_shift1 = 0, slot_shift2 = 0, slot_v1 = 0, slot_v2 = 0;
-    // Phase 2: drain this lane's FIFO (wavefront-wide loop, one code site).
-    auto drain = [&]() {
-        const int count = (int)(q_tail - q_base) / FORCE_BLOCK;
-        q_tail = q_base;
-        asm volatile("" : "+v"(q_tail));  // keep the tail an address, not base + count
-        int t_next = q_base[0];  // read one hit ahead: one LDS latency per trip, not two
-        for (int q = 0; q < count; q++) {
-            const int t = t_next;
-            t_next = q_base[min(q + 1, QUEUE_DEPTH - 1) * FORCE_BLOCK];
-            const Entry<Pt> other = sh_e[t];
-            const float4 v =
-                sorted_v[t + (t >= slot_v2 ? slot_shift2 : (t >= slot_v1 ? slot_shift1 : slot_shift0))];
-            Pt r = Xi - other.X;
-            float dist = dist3(r.x, r.y, r.z);
-            const int j = other.id;
-            F += pw_int(Xi, r, dist, i, j);
-            float friction = pw_friction(Xi, r, dist, i, j);
-            sum_friction += friction;
-            if (friction != 0) {
-                sum_v.x += friction * v.x;
-                sum_v.y += friction * v.y;
-                sum_v.z += friction * v.z;
-            }
-        }
-    };
-    auto dist2_to = [&](const int t) {
-        const float dx = Xi.x - sh_e[t].X.x;
-        const float dy = Xi.y - sh_e[t].X.y;
-        const float dz = Xi.z - sh_e[t].X.z;
-        return fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-    };
+    int anchor0 = 0, anchor1 = 0, anchor2 = 0;  // LDS index a queued offset is relative to
 
     for (int plane = 0; plane < 3; plane++) {
         // The plane's three rows, concatenated: row r occupies [v0[r], v0[r+1]).
@@ -490,29 +472,31 @@ __global__ __launch_bounds__(FORCE_BLOCK) void grid_force(const int n,
             int row = 0;
             int t = max(k_begin[0] - wg_begin[0], chunk) - chunk;
             int b = min(k_end[0] - wg_begin[0], chunk + chunk_n) - chunk;
+            anchor0 = t;
+            int off = 0;  // t - anchor of the row; a queued byte is (row << 6) | off
             while (true) {
-#ifndef YA_GROUP
-#define YA_GROUP 4
-#endif
-                while (t + YA_GROUP <= b && q_tail <= q_high) {
+                while (t + YA_GROUP <= b && q_tail <= q_high && off + YA_GROUP <= 64) {
                     float d2[YA_GROUP];
 #pragma unroll
-                    for (int u = 0; u < YA_GROUP; u++) d2[u] = dist2_to(t + u);
+                    for (int u = 0; u < YA_GROUP; u++) d2[u] = dist2(Xi, sh_e[t + u].X);
 #pragma unroll
                     for (int u = 0; u < YA_GROUP; u++) {
                         if (d2[u] < cut2) {
-                            *q_tail = (unsigned short)(t + u);
+                            *q_tail = (unsigned char)((row << 6) + off + u);
                             q_tail += FORCE_BLOCK;
                         }
                     }
                     t += YA_GROUP;
+                    off += YA_GROUP;
                 }
-                while (t < b && q_tail <= q_last && (t + YA_GROUP > b || q_tail > q_high)) {
-                    if (dist2_to(t) < cut2) {
-                        *q_tail = (unsigned short)t;
+                while (t < b && q_tail <= q_last && off < 64 &&
+                       (t + YA_GROUP > b || q_tail > q_high || off + YA_GROUP > 64)) {
+                    if (dist2(Xi, sh_e[t].X) < cut2) {
+                        *q_tail = (unsigned char)((row << 6) + off);
                         q_tail += FORCE_BLOCK;
                     }
                     t++;
+                    off++;
                 }
                 const bool row_done = !__any(t < b);
                 if (row_done && row < 2) {
@@ -523,10 +507,48 @@ __global__ __launch_bounds__(FORCE_BLOCK) void grid_force(const int n,
                                             : k_end[2] - wg_begin[2] + v0[2];
                     t = max(kb, chunk) - chunk;
                     b = min(ke, chunk + chunk_n) - chunk;
+                    off = 0;
+                    if (row == 1)
+                        anchor1 = t;
+                    else
+                        anchor2 = t;
                     continue;
                 }
-                drain();  // phase 2
+                {  // phase 2: drain this lane's FIFO (no lambda: nothing may have its address
+                   // taken here, the byte stores of phase 1 could alias it)
+                const int count = (int)(q_tail - q_base) / FORCE_BLOCK;
+                q_tail = q_base;
+                asm volatile("" : "+v"(q_tail));  // keep the tail an address, not base + count
+                int e_next = q_base[0];  // read one hit ahead: one LDS latency per trip, not two
+                for (int q = 0; q < count; q++) {
+                    const int e = e_next;
+                    e_next = q_base[min(q + 1, QUEUE_DEPTH - 1) * FORCE_BLOCK];
+                    const int t = (e & 63) + (e >= 128 ? anchor2 : (e >= 64 ? anchor1 : anchor0));
+                    const Entry<Pt> other = sh_e[t];
+                    const float4 v =
+                        sorted_v[t + (t >= slot_v2 ? slot_shift2 : (t >= slot_v1 ? slot_shift1 : slot_shift0))];
+                    Pt r = Xi - other.X;
+                    float dist = dist3(r.x, r.y, r.z);
+                    const int j = other.id;
+                    F += pw_int(Xi, r, dist, i, j);
+                    float friction = pw_friction(Xi, r, dist, i, j);
+                    sum_friction += friction;
+                    if (friction != 0) {
+                        sum_v.x += friction * v.x;
+                        sum_v.y += friction * v.y;
+                        sum_v.z += friction * v.z;
+                    }
+                }
+                }
                 if (row_done) break;
+                // FIFOs are empty: lanes still inside this row re-anchor at their position
+                off = 0;
+                if (row == 0)
+                    anchor0 = t;
+                else if (row == 1)
+                    anchor1 = t;
+                else
+                    anchor2 = t;
             }
         }
     }
