@@ -191,3 +191,24 @@ def test_pair_distance_sqrt_is_correctly_rounded_for_every_float(device):
     assert device.ya_check_sqrt(0x00000000, 0x7F800000) == 0
     # negative arguments and NaNs cannot arise from a sum of squares; still equal in class
     assert device.ya_check_sqrt(0x7F800001, 0x7F800100) == 0
+
+
+@pytest.mark.parametrize("dist,n", [(0.2, 6000), (0.12, 3000), (1.4, 3000)])
+def test_dense_and_sparse_systems_bit_exact(oracle, device, dist, n):
+    """Rarely taken paths of grid_force: rows longer than 64 candidates (re-anchoring),
+    FIFO overflow drains, planes that need several LDS chunks (dense: ~150-700 cells
+    per cube), and nearly empty stencils (sparse)."""
+    (Xo, vo, go), (Xd, vd, gd) = run_both(
+        oracle, device, "clipped_grid", n, 50, 1.0, dist, 11, 0.0005, 2)
+    for a, b in zip(go, gd):
+        assert np.array_equal(a[:n] if len(a) == n else a, b[:n] if len(b) == n else b)
+    assert np.array_equal(Xo.view(np.uint32), Xd.view(np.uint32))
+    assert np.array_equal(vo.view(np.uint32), vd.view(np.uint32))
+
+
+def test_dense_po_cell_bit_exact(oracle, device):
+    """The same stress with 24-byte entries (Po_cell: smaller LDS chunks)."""
+    n = 4000
+    (Xo, vo, _), (Xd, vd, _) = run_both(oracle, device, "relu_po_grid", n, 50, 1.0, 0.2, 3, 0.001, 2)
+    assert np.array_equal(Xo.view(np.uint32), Xd.view(np.uint32))
+    assert np.array_equal(vo.view(np.uint32), vd.view(np.uint32))
