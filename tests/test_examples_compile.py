@@ -42,15 +42,21 @@ def compile_model(tree, name):
            "-I" + os.path.join(ROOT, "include", "compat"),
            "-c", name + ".cu", "-o", str(tree / (name + ".o"))]
     proc = subprocess.run(cmd, cwd=tree / "examples", capture_output=True, text=True, timeout=900)
-    assert proc.returncode == 0, proc.stderr[-3000:]
+    return name, proc.returncode, proc.stderr[-3000:]
 
 
-@pytest.mark.parametrize("name", BASELINE_CONFIGS)
-def test_baseline_config_examples_compile_unchanged(tree, name):
-    compile_model(tree, name)
+def compile_all(tree, names):
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=6) as pool:   # hipcc runs as child processes
+        results = list(pool.map(lambda n: compile_model(tree, n), names))
+    failed = [(n, err) for n, rc, err in results if rc != 0]
+    assert not failed, failed
+
+
+def test_baseline_config_examples_compile_unchanged(tree):
+    compile_all(tree, BASELINE_CONFIGS)
 
 
 @pytest.mark.slow
-@pytest.mark.parametrize("name", OTHERS)
-def test_other_examples_compile_unchanged(tree, name):
-    compile_model(tree, name)
+def test_other_examples_compile_unchanged(tree):
+    compile_all(tree, OTHERS)
