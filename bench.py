@@ -50,6 +50,10 @@ def parse():
                     help="use the z-slab path (ghost exchange + all-reduce) even on 1 GPU")
     ap.add_argument("--force-variant", type=int, default=1,
                     help="1 = LDS-staged grid_force (default), 0 = grid_force_direct (A/B)")
+    ap.add_argument("--time-every", type=int, default=5,
+                    help="attach HIP events to every this-many-th force-kernel launch (odd: both stages)")
+    ap.add_argument("--sorted-pipeline", type=int, default=1,
+                    help="1 = second Heun stage built from the sorted cells (default), 0 = from d_X1 (A/B)")
     return ap.parse_args()
 
 
@@ -141,6 +145,7 @@ def main():
         sim.random_sphere(args.dist, 42)
         if "grid" in args.model:
             sim.set_param("force_variant", args.force_variant)
+            sim.set_param("sorted_pipeline", args.sorted_pipeline)
         if args.model.startswith("sorting"):
             sim.set_param("n_cells", n)
 
@@ -174,7 +179,9 @@ def main():
 
     advance(args.warmup)
     barrier()
-    sim.profile(True)
+    # HIP events on every 5th launch of the force kernel (both stages alternate):
+    # a timed launch costs a few microseconds of stream time, see DESIGN.md section 6
+    sim.profile(True, every=args.time_every)
     t0 = time.perf_counter()
     advance(args.steps)
     barrier()
@@ -234,7 +241,8 @@ def main():
                 "traffic": measured_traffic("grid_force_1M_springs") if world == 1 and n == 1_000_000 else None,
                 "bytes_per_launch": n_force * FORCE_BYTES_PER_CELL,
                 "avg_launch_us": force_s * 1e6,
-                "launches": launches,
+                "timed_launches": launches,
+                "launches": 2 * args.steps,
                 "whole_step_achieved_GBs": STEP_BYTES_PER_CELL * value / world / 1e9,
             },
         }

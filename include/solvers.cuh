@@ -35,6 +35,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <assert.h>
 #include <math.h>
@@ -152,19 +153,30 @@ __global__ void check_sqrt_all(unsigned first, unsigned last, unsigned long long
 }
 
 // Optional HIP-event timing of the force-kernel launches (bench.py's roofline
-// leg).  Disabled by default; when disabled mark() is a no-op.
+// leg).  The pair of events handed out by next() is attached to the kernel's own
+// dispatch (hipExtLaunchKernelGGL), so that timing a launch puts no extra packet
+// into the stream.  Even so a timed launch is a few microseconds slower end to end,
+// so only every `stride`-th launch is timed (use an odd stride to see both Heun
+// stages).  Disabled by default: next() then hands out null events.
 class Profiler {
 public:
-    void enable(bool on) { enabled = on; }
-    void mark()
+    void enable(bool on, int every = 1)
     {
-        if (!enabled) return;
-        if (used == events.size()) {
+        enabled = on;
+        stride = every > 0 ? every : 1;
+        seen = 0;
+    }
+    void next(hipEvent_t* start, hipEvent_t* stop)
+    {
+        *start = *stop = nullptr;
+        if (!enabled || seen++ % stride != 0) return;
+        while (used + 2 > events.size()) {
             hipEvent_t e;
             YA_CHECK((int)hipEventCreate(&e));
             events.push_back(e);
         }
-        YA_CHECK((int)hipEventRecord(events[used++], nullptr));
+        *start = events[used++];
+        *stop = events[used++];
     }
     // Sum of (after - before) over the recorded launches; resets the record.
     void read(double* total_ms, int* launches)
@@ -187,6 +199,8 @@ public:
 
 private:
     bool enabled = false;
+    int stride = 1;
+    long seen = 0;
     size_t used = 0;
     std::vector<hipEvent_t> events;
 };
@@ -201,7 +215,7 @@ bool is_no_gen_forces(const Generic_forces<Pt>& f)
 
 // dX = gen + F, then the friction term of add_rhs (solvers.cuh:146-161).
 template<typename Pt>
-__device__ __forceinline__ void store_rhs(
+__device__ __forceinline__ Pt store_rhs(
     Pt* __restrict__ d_dX, int i, bool has_gen, Pt F, float3 sum_v, float sum_friction)
 {
     Pt dX;
@@ -217,6 +231,7 @@ __device__ __forceinline__ void store_rhs(
         dX.z += sum_v.z / sum_friction;
     }
     d_dX[i] = dX;
+    return dX;
 }
 
 // All-pairs force (replaces compute_tile, solvers.cuh:284-322): j ascending,
@@ -337,6 +352,29 @@ inline float cutoff_squared(float cube_size)
     return t;
 }
 
+// The first 16 bytes of a staged cell (x, y, z and one more word).  Entries whose
+// size is a multiple of 16 bytes are read as one 16-byte LDS access: 4 LDS cycles
+// per wavefront, where the 12-byte form the compiler picks for x, y, z alone takes
+// 8 (MI355X_MICROARCH.md, section LDS).  keep_wide() is what stops it narrowing.
+template<typename Pt>
+__device__ __forceinline__ float4 staged_words(const Entry<Pt>* e)
+{
+    if constexpr (sizeof(Entry<Pt>) % 16 == 0)
+        return *reinterpret_cast<const float4*>(e);
+    else
+        return float4{e->X.x, e->X.y, e->X.z, 0.f};
+}
+__device__ __forceinline__ void keep_wide(const float4& w) { asm volatile("" ::"v"(w.w)); }
+
+template<typename Pt>
+__device__ __forceinline__ float dist2_to(const Pt& a, const float4 b)
+{
+    const float dx = a.x - b.x;
+    const float dy = a.y - b.y;
+    const float dz = a.z - b.z;
+    return fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+}
+
 template<typename Pt>
 __device__ __forceinline__ float dist2(const Pt& a, const Pt& b)
 {
@@ -387,10 +425,10 @@ __global__ __launch_bounds__(FORCE_BLOCK) void grid_force(const int n,
     const Entry<Pt>* __restrict__ sorted, const float4* __restrict__ sorted_v,
     const int* __restrict__ cube_id, const int* __restrict__ offs, const int gs,
     const int n_cubes, const float cut2, Pt* __restrict__ d_dX, const bool has_gen,
-    const int n_active)
+    const int n_active, Pt* __restrict__ d_dX_sorted)
 {
     constexpr int CAP = Stage_cells<Pt>::value;
-    __shared__ Entry<Pt> sh_e[CAP + 8];  // slack: phase 1 reads whole groups
+    __shared__ __attribute__((aligned(16))) Entry<Pt> sh_e[CAP + 8];  // slack: phase 1 reads whole groups
     // One byte per queued hit: (row of the plane) << 6 | offset of the candidate from
     // the lane's anchor in that row (0..63).
     __shared__ unsigned char sh_q[QUEUE_DEPTH * FORCE_BLOCK];
@@ -428,8 +466,9 @@ __global__ __launch_bounds__(FORCE_BLOCK) void grid_force(const int n,
     // old_v of an interacting neighbour is read from global memory (L1/L2 hits, the
     // neighbours of a workgroup are a few contiguous slot ranges) rather than staged,
     // which keeps the workgroup at 40 KiB of LDS = four workgroups per CU.
-    int slot_shift0 = 0, slot_shift1 = 0, slot_shift2 = 0, slot_v1 = 0, slot_v2 = 0;
+    int slot_shift0 = 0, slot_shift1 = 0, slot_shift2 = 0;
     int anchor0 = 0, anchor1 = 0, anchor2 = 0;  // LDS index a queued offset is relative to
+    int slot0 = 0, slot1 = 0, slot2 = 0;        // the same anchors as slots of the sorted arrays
 
     for (int plane = 0; plane < 3; plane++) {
         // The plane's three rows, concatenated: row r occupies [v0[r], v0[r+1]).
@@ -460,8 +499,6 @@ __global__ __launch_bounds__(FORCE_BLOCK) void grid_force(const int n,
             slot_shift0 = wg_begin[0] + chunk;
             slot_shift1 = wg_begin[1] - v0[1] + chunk;
             slot_shift2 = wg_begin[2] - v0[2] + chunk;
-            slot_v1 = v0[1] - chunk;
-            slot_v2 = v0[2] - chunk;
 
             // One wavefront-uniform loop over the plane's rows.  Phase 1: each lane
             // walks its candidates of the current row, four per trip (their LDS reads
@@ -473,12 +510,19 @@ __global__ __launch_bounds__(FORCE_BLOCK) void grid_force(const int n,
             int t = max(k_begin[0] - wg_begin[0], chunk) - chunk;
             int b = min(k_end[0] - wg_begin[0], chunk + chunk_n) - chunk;
             anchor0 = t;
+            slot0 = t + slot_shift0;
             int off = 0;  // t - anchor of the row; a queued byte is (row << 6) | off
             while (true) {
                 while (t + YA_GROUP <= b && q_tail <= q_high && off + YA_GROUP <= 64) {
+                    float4 w[YA_GROUP];
                     float d2[YA_GROUP];
 #pragma unroll
-                    for (int u = 0; u < YA_GROUP; u++) d2[u] = dist2(Xi, sh_e[t + u].X);
+                    for (int u = 0; u < YA_GROUP; u++) w[u] = staged_words(&sh_e[t + u]);
+#pragma unroll
+                    for (int u = 0; u < YA_GROUP; u++) {
+                        d2[u] = dist2_to(Xi, w[u]);
+                        keep_wide(w[u]);
+                    }
 #pragma unroll
                     for (int u = 0; u < YA_GROUP; u++) {
                         if (d2[u] < cut2) {
@@ -491,7 +535,9 @@ __global__ __launch_bounds__(FORCE_BLOCK) void grid_force(const int n,
                 }
                 while (t < b && q_tail <= q_last && off < 64 &&
                        (t + YA_GROUP > b || q_tail > q_high || off + YA_GROUP > 64)) {
-                    if (dist2(Xi, sh_e[t].X) < cut2) {
+                    const float4 w = staged_words(&sh_e[t]);
+                    keep_wide(w);
+                    if (dist2_to(Xi, w) < cut2) {
                         *q_tail = (unsigned char)((row << 6) + off);
                         q_tail += FORCE_BLOCK;
                     }
@@ -508,10 +554,13 @@ __global__ __launch_bounds__(FORCE_BLOCK) void grid_force(const int n,
                     t = max(kb, chunk) - chunk;
                     b = min(ke, chunk + chunk_n) - chunk;
                     off = 0;
-                    if (row == 1)
+                    if (row == 1) {
                         anchor1 = t;
-                    else
+                        slot1 = t + slot_shift1;
+                    } else {
                         anchor2 = t;
+                        slot2 = t + slot_shift2;
+                    }
                     continue;
                 }
                 {  // phase 2: drain this lane's FIFO (no lambda: nothing may have its address
@@ -525,8 +574,8 @@ __global__ __launch_bounds__(FORCE_BLOCK) void grid_force(const int n,
                     e_next = q_base[min(q + 1, QUEUE_DEPTH - 1) * FORCE_BLOCK];
                     const int t = (e & 63) + (e >= 128 ? anchor2 : (e >= 64 ? anchor1 : anchor0));
                     const Entry<Pt> other = sh_e[t];
-                    const float4 v =
-                        sorted_v[t + (t >= slot_v2 ? slot_shift2 : (t >= slot_v1 ? slot_shift1 : slot_shift0))];
+                    const unsigned slot = (e & 63) + (e >= 128 ? slot2 : (e >= 64 ? slot1 : slot0));
+                    const float4 v = sorted_v[slot];
                     Pt r = Xi - other.X;
                     float dist = dist3(r.x, r.y, r.z);
                     const int j = other.id;
@@ -543,16 +592,23 @@ __global__ __launch_bounds__(FORCE_BLOCK) void grid_force(const int n,
                 if (row_done) break;
                 // FIFOs are empty: lanes still inside this row re-anchor at their position
                 off = 0;
-                if (row == 0)
+                if (row == 0) {
                     anchor0 = t;
-                else if (row == 1)
+                    slot0 = t + slot_shift0;
+                } else if (row == 1) {
                     anchor1 = t;
-                else
+                    slot1 = t + slot_shift1;
+                } else {
                     anchor2 = t;
+                    slot2 = t + slot_shift2;
+                }
             }
         }
     }
-    if (active) store_rhs(d_dX, i, has_gen, F, sum_v, sum_friction);
+    if (active) {
+        const Pt dX = store_rhs(d_dX, i, has_gen, F, sum_v, sum_friction);
+        if (d_dX_sorted) d_dX_sorted[s] = dX;  // for the sorted-space Euler stage
+    }
 }
 
 // Gabriel-graph force (replaces compute_cube_gabriel, solvers.cuh:509-602): the
@@ -707,6 +763,53 @@ __global__ __launch_bounds__(ya::UPDATE_BLOCK) void heun_step(const int n, const
 }
 
 
+// The same two updates for the sorted-space pipeline of Grid_solver (no generic
+// forces): the predictor X1 = X0 + (dX - fix) dt is applied in place to the
+// cube-sorted copy of the cells, which then feeds the second grid build without
+// any gather; d_dX keeps the raw right-hand side and the corrector subtracts both
+// fixed velocities itself.  Statement for statement the arithmetic of
+// euler_step / heun_step above.
+template<typename Pt>
+__global__ __launch_bounds__(ya::UPDATE_BLOCK) void euler_step_sorted(const int n, const float dt,
+    const float* __restrict__ d_fix, const Pt* __restrict__ d_dX_sorted,
+    ya::Entry<Pt>* __restrict__ d_sorted)
+{
+    const int s = blockIdx.x * ya::UPDATE_BLOCK + threadIdx.x;
+    if (s >= n) return;
+
+    Pt dX = d_dX_sorted[s];
+    dX.x -= d_fix[0];
+    dX.y -= d_fix[1];
+    dX.z -= d_fix[2];
+    ya::Entry<Pt> e = d_sorted[s];
+    e.X = e.X + dX * dt;
+    d_sorted[s] = e;
+}
+
+template<typename Pt>
+__global__ __launch_bounds__(ya::UPDATE_BLOCK) void heun_step_raw(const int n, const float dt,
+    const Pt* __restrict__ d_dX, const float* __restrict__ d_fix, const Pt* __restrict__ d_dX1,
+    const float* __restrict__ d_fix1, Pt* __restrict__ d_X, float3* __restrict__ d_old_v)
+{
+    const int i = blockIdx.x * ya::UPDATE_BLOCK + threadIdx.x;
+    if (i >= n) return;
+
+    Pt dX = d_dX[i];
+    dX.x -= d_fix[0];
+    dX.y -= d_fix[1];
+    dX.z -= d_fix[2];
+    Pt dX1 = d_dX1[i];
+    dX1.x -= d_fix1[0];
+    dX1.y -= d_fix1[1];
+    dX1.z -= d_fix1[2];
+    Pt X = d_X[i];
+    X += (dX + dX1) * 0.5 * dt;
+    d_X[i] = X;
+    d_old_v[i] = float3{
+        (dX.x + dX1.x) * 0.5f, (dX.y + dX1.y) * 0.5f, (dX.z + dX1.z) * 0.5f};
+}
+
+
 // Solution<Pt, Solver> combines a method, Solver, with a point type, Pt: host
 // mirror of the variables plus access to the device arrays (solvers.cuh:56-106).
 template<typename Pt, template<typename> class Solver>
@@ -793,7 +896,9 @@ public:
         YA_CHECK(ya_memset_async(d_old_v, 0, (size_t)n_max * sizeof(float3), nullptr));
         YA_CHECK(ya_malloc((void**)&d_n, sizeof(int)));
         YA_CHECK(ya_malloc((void**)&d_mean, 2 * sizeof(Pt)));
+        YA_CHECK(ya_malloc((void**)&d_mean_first, 2 * sizeof(Pt)));
         YA_CHECK(ya_malloc((void**)&d_fix, 4 * sizeof(float)));
+        YA_CHECK(ya_malloc((void**)&d_fix_first, 4 * sizeof(float)));
         YA_CHECK(ya_malloc((void**)&d_workspace, ya_reduce_workspace_bytes(n_floats)));
     }
     ~Heun_solver()
@@ -805,7 +910,9 @@ public:
         ya_free(d_old_v);
         ya_free(d_n);
         ya_free(d_mean);
+        ya_free(d_mean_first);
         ya_free(d_fix);
+        ya_free(d_fix_first);
         ya_free(d_workspace);
     }
     Heun_solver(const Heun_solver&) = delete;
@@ -827,7 +934,7 @@ protected:
     Pt *d_X, *d_dX, *d_X1, *d_dX1;
     float3* d_old_v;
     int* d_n;
-    float *d_mean, *d_fix, *d_workspace;
+    float *d_mean, *d_fix, *d_mean_first, *d_fix_first, *d_workspace;
     bool fix_com = true;
     bool fix_com_z = false;
     int fix_point = 0;
@@ -842,16 +949,18 @@ protected:
     void check_status() { Computer<Pt>::check_status(); }
 
     // The velocity subtracted from dX.xyz for this stage, left in device memory.
-    const float* fix_velocity(int n, Pt* d_rhs, bool mean, bool point_xy)
+    const float* fix_velocity(int n, Pt* d_rhs, bool mean, bool point_xy, bool first = false)
     {
+        float* mean_out = first ? d_mean_first : d_mean;
+        float* fix_out = first ? d_fix_first : d_fix;
         if (mean) {  // solvers.cuh:241-249 / :266-268
-            YA_CHECK(ya_reduce_mean(d_rhs, n_floats, n, d_mean, d_workspace, nullptr));
-            if (!point_xy) return d_mean;
-            ya::make_fix<Pt><<<1, 1>>>(2, d_mean, d_rhs + fix_point, d_fix);
-            return d_fix;
+            YA_CHECK(ya_reduce_mean(d_rhs, n_floats, n, mean_out, d_workspace, nullptr));
+            if (!point_xy) return mean_out;
+            ya::make_fix<Pt><<<1, 1>>>(2, mean_out, d_rhs + fix_point, fix_out);
+            return fix_out;
         }
-        ya::make_fix<Pt><<<1, 1>>>(1, d_mean, d_rhs + fix_point, d_fix);  // :250-253
-        return d_fix;
+        ya::make_fix<Pt><<<1, 1>>>(1, mean_out, d_rhs + fix_point, fix_out);  // :250-253
+        return fix_out;
     }
 
     // The three pieces of a stage (stage 1 works on d_X -> d_dX, stage 2 on
@@ -869,7 +978,7 @@ protected:
             gen_forces(n, d_in, d_rhs);
         }
         Computer<Pt>::template pwints<pw_int, pw_friction>(
-            n, d_in, d_old_v, d_rhs, has_gen, n_active);
+            n, d_in, d_old_v, d_rhs, has_gen, n_active, false);
     }
     // sum and mean of the stage's right-hand side over the first n points, left on
     // the device as {mean[n_floats], sum[n_floats]}
@@ -895,6 +1004,22 @@ protected:
         const int n = get_d_n();
         if (n <= 0) return;
 
+        if (Computer<Pt>::use_sorted_pipeline() && ya::is_no_gen_forces<Pt>(gen_forces)) {
+            // Sorted-space pipeline: the predictor lives in the cube-sorted copy of
+            // the cells, so the second grid build gathers nothing and d_X1 is never
+            // materialised.  Same arithmetic, same results.
+            const int blocks = (n + ya::UPDATE_BLOCK - 1) / ya::UPDATE_BLOCK;
+            Computer<Pt>::template pwints<pw_int, pw_friction>(n, d_X, d_old_v, d_dX, false, n, true);
+            // this stage's fixed velocity has to outlive the next reduction
+            const float* fix = fix_velocity(n, d_dX, fix_com or fix_com_z, fix_com_z, true);
+            Computer<Pt>::predictor_in_sorted_space(n, dt, fix);
+            Computer<Pt>::template pwints_from_sorted<pw_int, pw_friction>(n, d_dX1);
+            const float* fix1 = fix_velocity(n, d_dX1, fix_com, false);
+            heun_step_raw<<<blocks, ya::UPDATE_BLOCK>>>(
+                n, dt, d_dX, fix, d_dX1, fix1, d_X, d_old_v);
+            return;
+        }
+
         // 1st stage
         stage_rhs<pw_int, pw_friction>(1, n, n, gen_forces);
         stage_update(1, n, dt, fix_velocity(n, d_dX, fix_com or fix_com_z, fix_com_z));
@@ -915,19 +1040,23 @@ class Tile_computer {
 public:
     Tile_computer(int n_max) {}
     ya::Profiler profiler;
+    bool use_sorted_pipeline() const { return false; }
 
 protected:
     void check_status() {}
+    void predictor_in_sorted_space(int, float, const float*) {}
+    template<Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction>
+    void pwints_from_sorted(int, Pt*) {}
     template<Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction>
     void pwints(const int n, const Pt* __restrict__ d_X, const float3* __restrict__ d_old_v,
-        Pt* d_dX, const bool has_gen, const int n_active)
+        Pt* d_dX, const bool has_gen, const int n_active, const bool keep_sorted)
     {
         assert(n_active == n);  // Tile_solver is single-GPU only (all pairs)
-        profiler.mark();
-        ya::tile_force<Pt, pw_int, pw_friction>
-            <<<(n + ya::TILE_BLOCK - 1) / ya::TILE_BLOCK, ya::TILE_BLOCK>>>(
-                n, d_X, d_old_v, d_dX, has_gen);
-        profiler.mark();
+        hipEvent_t start, stop;
+        profiler.next(&start, &stop);
+        hipExtLaunchKernelGGL((ya::tile_force<Pt, pw_int, pw_friction>),
+            dim3((n + ya::TILE_BLOCK - 1) / ya::TILE_BLOCK), dim3(ya::TILE_BLOCK), 0, nullptr,
+            start, stop, 0, n, d_X, d_old_v, d_dX, has_gen);
     }
 };
 
@@ -978,6 +1107,15 @@ public:
         YA_CHECK(ya_grid_build_sorted(handle, d_X, sizeof(Pt), d_old_v, n, cube_size, d_sorted,
             sizeof(ya::Entry<Pt>), d_sorted_v, nullptr));
     }
+    // Same result as build_sorted on the cells held (in any order) by d_prev, read
+    // from those entries themselves: nothing is gathered through point ids.
+    template<typename Pt>
+    void rebuild_sorted(const int n, const ya::Entry<Pt>* d_prev, const float4* d_prev_v,
+        const float cube_size, ya::Entry<Pt>* d_sorted, float4* d_sorted_v)
+    {
+        YA_CHECK(ya_grid_rebuild_sorted(handle, d_prev, sizeof(ya::Entry<Pt>), sizeof(Pt),
+            d_prev_v, n, cube_size, d_sorted, d_sorted_v, nullptr));
+    }
     const int* offsets() const { return d_offs; }
     void check_status()
     {
@@ -1021,35 +1159,66 @@ public:
         YA_CHECK((int)hipMemcpyToSymbol(HIP_SYMBOL(d_nhood), h_nhood, sizeof(h_nhood)));
         YA_CHECK(ya_malloc((void**)&d_sorted, (size_t)n_max * sizeof(ya::Entry<Pt>)));
         YA_CHECK(ya_malloc((void**)&d_sorted_v, (size_t)n_max * sizeof(float4)));
+        YA_CHECK(ya_malloc((void**)&d_resorted, (size_t)n_max * sizeof(ya::Entry<Pt>)));
+        YA_CHECK(ya_malloc((void**)&d_resorted_v, (size_t)n_max * sizeof(float4)));
+        YA_CHECK(ya_malloc((void**)&d_dX_sorted, (size_t)n_max * sizeof(Pt)));
     }
     ~Grid_computer()
     {
         ya_free(d_sorted);
         ya_free(d_sorted_v);
+        ya_free(d_resorted);
+        ya_free(d_resorted_v);
+        ya_free(d_dX_sorted);
     }
     Grid_computer(const Grid_computer&) = delete;
+    bool sorted_pipeline = true;  // false = both stages through d_X / d_X1 (A/B)
+    bool use_sorted_pipeline() const { return sorted_pipeline and force_variant != 0; }
 
 protected:
     Grid grid;
-    ya::Entry<Pt>* d_sorted;
-    float4* d_sorted_v;
+    ya::Entry<Pt>*d_sorted, *d_resorted;
+    float4 *d_sorted_v, *d_resorted_v;
+    Pt* d_dX_sorted;
     void check_status() { grid.check_status(); }
     template<Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction>
+    void forces(const int n, const ya::Entry<Pt>* d_cells, const float4* d_cells_v, Pt* d_dX,
+        const bool has_gen, const int n_active, Pt* d_dX_in_cell_order)
+    {
+        const int blocks = (n + ya::FORCE_BLOCK - 1) / ya::FORCE_BLOCK;
+        hipEvent_t start, stop;
+        profiler.next(&start, &stop);
+        if (force_variant == 0)
+            hipExtLaunchKernelGGL((ya::grid_force_direct<Pt, pw_int, pw_friction>), dim3(blocks),
+                dim3(ya::FORCE_BLOCK), 0, nullptr, start, stop, 0, n, d_cells, d_cells_v,
+                (const int*)grid.d_cube_id, grid.offsets(), grid.grid_size, grid.n_cubes,
+                cube_size, d_dX, has_gen, n_active);
+        else
+            hipExtLaunchKernelGGL((ya::grid_force<Pt, pw_int, pw_friction>), dim3(blocks),
+                dim3(ya::FORCE_BLOCK), 0, nullptr, start, stop, 0, n, d_cells, d_cells_v,
+                (const int*)grid.d_cube_id, grid.offsets(), grid.grid_size, grid.n_cubes,
+                ya::cutoff_squared(cube_size), d_dX, has_gen, n_active, d_dX_in_cell_order);
+    }
+    template<Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction>
     void pwints(const int n, const Pt* __restrict__ d_X, const float3* __restrict__ d_old_v,
-        Pt* d_dX, const bool has_gen, const int n_active)
+        Pt* d_dX, const bool has_gen, const int n_active, const bool keep_sorted)
     {
         grid.build_sorted(n, d_X, d_old_v, cube_size, d_sorted, d_sorted_v);
-        const int blocks = (n + ya::FORCE_BLOCK - 1) / ya::FORCE_BLOCK;
-        profiler.mark();
-        if (force_variant == 0)
-            ya::grid_force_direct<Pt, pw_int, pw_friction><<<blocks, ya::FORCE_BLOCK>>>(n,
-                d_sorted, d_sorted_v, grid.d_cube_id, grid.offsets(), grid.grid_size,
-                grid.n_cubes, cube_size, d_dX, has_gen, n_active);
-        else
-            ya::grid_force<Pt, pw_int, pw_friction><<<blocks, ya::FORCE_BLOCK>>>(n, d_sorted,
-                d_sorted_v, grid.d_cube_id, grid.offsets(), grid.grid_size, grid.n_cubes,
-                ya::cutoff_squared(cube_size), d_dX, has_gen, n_active);
-        profiler.mark();
+        forces<pw_int, pw_friction>(n, d_sorted, d_sorted_v, d_dX, has_gen, n_active,
+            keep_sorted ? d_dX_sorted : nullptr);
+    }
+    // The two halves of the second Heun stage when the first one kept its
+    // right-hand side in cell order (Heun_solver::take_step).
+    void predictor_in_sorted_space(const int n, const float dt, const float* d_fix)
+    {
+        euler_step_sorted<<<(n + ya::UPDATE_BLOCK - 1) / ya::UPDATE_BLOCK, ya::UPDATE_BLOCK>>>(
+            n, dt, d_fix, d_dX_sorted, d_sorted);
+    }
+    template<Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction>
+    void pwints_from_sorted(const int n, Pt* d_dX)
+    {
+        grid.rebuild_sorted(n, d_sorted, d_sorted_v, cube_size, d_resorted, d_resorted_v);
+        forces<pw_int, pw_friction>(n, d_resorted, d_resorted_v, d_dX, false, n, nullptr);
     }
 };
 
@@ -1067,11 +1236,12 @@ public:
         int n_max, int grid_size = 50, float cube_size = 1, float gabriel_coefficient = 0.8)
         : Grid_computer<Pt>{n_max, grid_size, cube_size}, gabriel_coefficient{gabriel_coefficient}
     {}
+    bool use_sorted_pipeline() const { return false; }
 
 protected:
     template<Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction>
     void pwints(const int n, const Pt* __restrict__ d_X, const float3* __restrict__ d_old_v,
-        Pt* d_dX, const bool has_gen, const int n_active)
+        Pt* d_dX, const bool has_gen, const int n_active, const bool keep_sorted)
     {
         assert(n_active == n);
         this->grid.build_sorted(n, d_X, d_old_v, this->cube_size, this->d_sorted, this->d_sorted_v);

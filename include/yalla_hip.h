@@ -29,7 +29,7 @@ extern "C" {
 /* The libraries are built with -fvisibility=hidden; only this C ABI is exported. */
 #pragma GCC visibility push(default)
 
-#define YA_ABI_VERSION 2
+#define YA_ABI_VERSION 3
 
 /* Status bits reported by ya_grid_status(). */
 #define YA_STATUS_OUT_OF_GRID 1 /* a cell's cube id fell outside [0, n_cubes):
@@ -90,6 +90,17 @@ int ya_grid_build(ya_grid* g, const void* d_X, size_t stride_bytes, int n,
 int ya_grid_build_sorted(ya_grid* g, const void* d_X, size_t stride_bytes,
     const void* d_old_v, int n, float cube_size, void* d_sorted_X,
     size_t entry_bytes, void* d_sorted_v, void* stream);
+
+/* The same result as ya_grid_build_sorted, but for cells that already sit in an
+ * earlier build's sorted arrays and have moved a little since (the second Heun
+ * stage): d_prev_sorted holds n entries {point (point_bytes), int id, padding to
+ * entry_bytes} whose positions are the current ones, d_prev_sorted_v their old_v
+ * (16 B each).  Nothing is gathered from the original-order arrays; the outputs
+ * (distinct buffers) and the four public arrays are exactly what a build from
+ * the original-order arrays would give. */
+int ya_grid_rebuild_sorted(ya_grid* g, const void* d_prev_sorted, size_t entry_bytes,
+    size_t point_bytes, const void* d_prev_sorted_v, int n, float cube_size, void* d_sorted_out,
+    void* d_sorted_v_out, void* stream);
 
 /* Sticky status bits (YA_STATUS_*); blocking 4-byte read.  `clear` != 0
  * resets them. */

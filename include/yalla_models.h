@@ -117,8 +117,9 @@ long ya_check_sqrt(unsigned first_bits, unsigned last_bits);
 int ya_sim_set_reduce_order(ya_sim* sim, int order);
 
 /* Device only: accumulate HIP-event timings of the dominant kernel's launches
- * (the force kernel) while enabled; read back as total milliseconds and launch
- * count.  Returns -1 on the oracle. */
+ * (the force kernel) while enabled -- every `enable`-th launch is timed, 1 = all,
+ * 0 = off; read back as total milliseconds and the number of timed launches.
+ * Returns -1 on the oracle. */
 int ya_sim_profile(ya_sim* sim, int enable);
 int ya_sim_profile_read(ya_sim* sim, double* total_ms, int* launches);
 

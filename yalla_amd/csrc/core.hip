@@ -221,6 +221,40 @@ __global__ __launch_bounds__(BLOCK) void k_order(const int* __restrict__ arrival
     }
 }
 
+// Re-sort of cells that are ALREADY in (an earlier) cube-sorted order, e.g. the
+// second Heun stage: positions moved a little, the previous sorted arrays are the
+// input, so every read is coalesced or local and nothing is gathered from the
+// original-order arrays.  arrival_src[slot] = index of the cell in the previous
+// sorted arrays; ids come from the previous entries (word ID_WORD of EW words).
+template<int EW>
+__global__ __launch_bounds__(BLOCK) void k_order_from(const int* __restrict__ arrival_src,
+    const int* __restrict__ cube_id_sorted, const int* __restrict__ offs, int n, int id_word,
+    const unsigned* __restrict__ prev_entries, const float4* __restrict__ prev_v,
+    int* __restrict__ point_id, int* __restrict__ next_prev_pid, unsigned* __restrict__ sorted_out,
+    float4* __restrict__ sorted_v_out)
+{
+    int s = blockIdx.x * BLOCK + threadIdx.x;
+    if (s >= n) return;
+    const int c = cube_id_sorted[s];
+    const int a = offs[c], b = offs[c + 1];
+    const int src = arrival_src[s];
+    const unsigned* mine = prev_entries + (size_t)src * EW;
+    const int p = (int)mine[id_word];
+    int smaller = 0;
+    for (int t = a; t < b; t++)
+        smaller += (int)prev_entries[(size_t)arrival_src[t] * EW + id_word] < p;
+    const int dst = a + smaller;
+    point_id[dst] = p;
+    next_prev_pid[dst] = p;
+    unsigned w[EW];
+#pragma unroll
+    for (int k = 0; k < EW; k++) w[k] = mine[k];
+    unsigned* out = sorted_out + (size_t)dst * EW;
+#pragma unroll
+    for (int k = 0; k < EW; k++) out[k] = w[k];
+    sorted_v_out[dst] = prev_v[src];
+}
+
 // --- deterministic reduction -----------------------------------------------
 // B = clamp(ceil(n/256), 1, 1024) blocks; lane (b, t) sums i = b*256 + t,
 // += B*256 ... serially; block folds 256 lanes by halving through LDS; then one
@@ -531,6 +565,61 @@ int ya_grid_build_sorted(ya_grid* g, const void* d_X, size_t stride_bytes,
                 return (int)hipErrorInvalidValue;  // points of > 16 floats: not built
         }
 #undef YA_ORDER
+    }
+    g->n_prev = n;
+    return (int)hipGetLastError();
+}
+
+int ya_grid_rebuild_sorted(ya_grid* g, const void* d_prev_sorted, size_t entry_bytes,
+    size_t point_bytes, const void* d_prev_sorted_v, int n, float cube_size, void* d_sorted_out,
+    void* d_sorted_v_out, void* stream)
+{
+    if (!g || n < 0 || n > g->n_max || point_bytes < 12 || entry_bytes < point_bytes + 4 ||
+        entry_bytes % 4 || point_bytes % 4 || !d_prev_sorted || !d_prev_sorted_v || !d_sorted_out ||
+        !d_sorted_v_out)
+        return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    const int entry_f = (int)(entry_bytes / 4);
+    const int nb = ceil_div(n, BLOCK);
+    // cells are read in the order they are stored: visit = identity (n_prev = 0)
+    if (n > 0)
+        k_bin<<<nb, BLOCK, 0, st>>>((const float*)d_prev_sorted, entry_f, n, cube_size, g->grid_size,
+            g->n_cubes, g->d_prev_pid, 0, g->d_cube_of, g->d_rank, g->d_count, g->d_status);
+    k_tile_sum<<<g->n_tiles, BLOCK, 0, st>>>(g->d_count, g->d_tile_sums);
+    k_scan<<<g->n_tiles, BLOCK, 0, st>>>(g->d_count, g->d_tile_sums, g->n_cubes, n, g->d_offs,
+        g->d_cube_start, g->d_cube_end);
+    if (n > 0) {
+        k_scatter<<<nb, BLOCK, 0, st>>>(g->d_cube_of, g->d_rank, g->d_offs, n, g->d_prev_pid, 0,
+            g->d_arrival, g->d_cube_id);
+        const int id_word = (int)(point_bytes / 4);
+#define YA_ORDER_FROM(EW)                                                                    \
+    case EW:                                                                                 \
+        k_order_from<EW><<<nb, BLOCK, 0, st>>>(g->d_arrival, g->d_cube_id, g->d_offs, n,     \
+            id_word, (const unsigned*)d_prev_sorted, (const float4*)d_prev_sorted_v,         \
+            g->d_point_id, g->d_prev_pid, (unsigned*)d_sorted_out, (float4*)d_sorted_v_out); \
+        break;
+        switch (entry_f) {
+            YA_ORDER_FROM(4)
+            YA_ORDER_FROM(5)
+            YA_ORDER_FROM(6)
+            YA_ORDER_FROM(7)
+            YA_ORDER_FROM(8)
+            YA_ORDER_FROM(9)
+            YA_ORDER_FROM(10)
+            YA_ORDER_FROM(11)
+            YA_ORDER_FROM(12)
+            YA_ORDER_FROM(13)
+            YA_ORDER_FROM(14)
+            YA_ORDER_FROM(15)
+            YA_ORDER_FROM(16)
+            YA_ORDER_FROM(17)
+            YA_ORDER_FROM(18)
+            YA_ORDER_FROM(19)
+            YA_ORDER_FROM(20)
+            default:
+                return (int)hipErrorInvalidValue;
+        }
+#undef YA_ORDER_FROM
     }
     g->n_prev = n;
     return (int)hipGetLastError();

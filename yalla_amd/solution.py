@@ -164,8 +164,9 @@ class Solution:
     def set_reduce_order(self, order):
         return self.lib.ya_sim_set_reduce_order(self._h, int(order))
 
-    def profile(self, enable):
-        return self.lib.ya_sim_profile(self._h, 1 if enable else 0)
+    def profile(self, enable, every=1):
+        """Time every `every`-th launch of the force kernel with HIP events."""
+        return self.lib.ya_sim_profile(self._h, int(every) if enable else 0)
 
     def profile_read(self):
         ms = C.c_double()
