@@ -152,6 +152,35 @@ __global__ void check_sqrt_all(unsigned first, unsigned last, unsigned long long
     if (bad) atomicAdd(mismatches, bad);
 }
 
+// Workgroup -> tile mapping that gives each of the 8 XCDs one contiguous range of
+// tiles.  The dispatcher places block b on XCD b % 8 (MI355X_MICROARCH.md, workgroup
+// dispatch): with the identity mapping every XCD's 4 MiB L2 sees the whole sorted
+// array; with this one it sees an eighth of it, which is about what it can hold at
+// 10^6 cells, so the stencil rows a tile reads (the tiles before and after it, one
+// grid row and one grid plane away) are L2 hits.  Bijective for any grid size; a
+// wrong placement guess would cost speed, not correctness.
+__device__ __forceinline__ int xcd_contiguous_tile(const int block, const int n_blocks)
+{
+    constexpr int XCDS = 8;
+    const int xcd = block % XCDS, turn = block / XCDS;
+    const int q = n_blocks / XCDS, r = n_blocks % XCDS;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + turn;
+}
+
+// Test hook: the same for ya::reciprocal (dtypes.cuh) against 1.0f / x.
+__global__ void check_reciprocal_all(
+    unsigned first, unsigned last, unsigned long long* mismatches)
+{
+    unsigned long long bad = 0;
+    for (unsigned long long u = (unsigned long long)first + blockIdx.x * blockDim.x + threadIdx.x;
+         u <= last; u += (unsigned long long)gridDim.x * blockDim.x) {
+        const float x = __int_as_float((int)(unsigned)u);
+        const float a = reciprocal(x), b = 1.0f / x;
+        if (__float_as_int(a) != __float_as_int(b) && !(a != a && b != b)) bad++;
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
 // Optional HIP-event timing of the force-kernel launches (bench.py's roofline
 // leg).  The pair of events handed out by next() is attached to the kernel's own
 // dispatch (hipExtLaunchKernelGGL), so that timing a launch puts no extra packet
@@ -432,6 +461,7 @@ __global__ __launch_bounds__(FORCE_BLOCK) void grid_force(const int n,
     // One byte per queued hit: (row of the plane) << 6 | offset of the candidate from
     // the lane's anchor in that row (0..63).
     __shared__ unsigned char sh_q[QUEUE_DEPTH * FORCE_BLOCK];
+
     // LDS (address space 3) FIFO pointers: 32-bit address arithmetic in the hot loops
     using Lds_u16 = __attribute__((address_space(3))) unsigned char;
     Lds_u16* const q_base = (Lds_u16*)sh_q + threadIdx.x;          // this lane's FIFO, stride 256
@@ -440,7 +470,11 @@ __global__ __launch_bounds__(FORCE_BLOCK) void grid_force(const int n,
 #endif
     Lds_u16* const q_high = q_base + (QUEUE_DEPTH - YA_GROUP) * FORCE_BLOCK;  // "nearly full" mark
 
+#ifdef YA_NO_XCD_MAPPING
     const int s0 = blockIdx.x * FORCE_BLOCK;
+#else
+    const int s0 = xcd_contiguous_tile(blockIdx.x, gridDim.x) * FORCE_BLOCK;
+#endif
     const int s = s0 + threadIdx.x;
     bool active = s < n;
     const int c_lo = cube_id[s0];
@@ -516,6 +550,7 @@ __global__ __launch_bounds__(FORCE_BLOCK) void grid_force(const int n,
                 while (t + YA_GROUP <= b && q_tail <= q_high && off + YA_GROUP <= 64) {
                     float4 w[YA_GROUP];
                     float d2[YA_GROUP];
+
 #pragma unroll
                     for (int u = 0; u < YA_GROUP; u++) w[u] = staged_words(&sh_e[t + u]);
 #pragma unroll

@@ -111,6 +111,8 @@ int ya_slab_get_own(ya_sim* sim, float* X_host, int* global_ids_host);
  * which the engine's correctly rounded square root (ya::exact_sqrt, used for every
  * pair distance) differs from sqrtf.  Returns -1 on the oracle. */
 long ya_check_sqrt(unsigned first_bits, unsigned last_bits);
+/* The same for the reciprocal behind `Pt / float` (ya::reciprocal) against 1.0f / x. */
+long ya_check_reciprocal(unsigned first_bits, unsigned last_bits);
 
 /* Oracle only: 0 = serial COM sum, 1 = the engine's documented tree order.
  * Returns -1 on the device build. */

@@ -193,6 +193,13 @@ def test_pair_distance_sqrt_is_correctly_rounded_for_every_float(device):
     assert device.ya_check_sqrt(0x7F800001, 0x7F800100) == 0
 
 
+def test_point_division_reciprocal_is_correctly_rounded_for_every_float(device):
+    """ya::reciprocal (the factor of `Pt / float`, reference dtypes.cuh:202-217) against
+    the IEEE 1.0f / x for ALL binary32 bit patterns of either sign."""
+    assert device.ya_check_reciprocal(0x00000000, 0x7FFFFFFF) == 0
+    assert device.ya_check_reciprocal(0x80000000, 0xFFFFFFFF) == 0
+
+
 @pytest.mark.parametrize("dist,n", [(0.2, 6000), (0.12, 3000), (1.4, 3000)])
 def test_dense_and_sparse_systems_bit_exact(oracle, device, dist, n):
     """Rarely taken paths of grid_force: rows longer than 64 candidates (re-anchoring),

@@ -58,6 +58,7 @@ MODELS_ABI = {
     "ya_slab_n_own": (C.c_int, [_sim]),
     "ya_slab_get_own": (C.c_int, [_sim, _pf, _pi]),
     "ya_check_sqrt": (C.c_long, [C.c_uint, C.c_uint]),
+    "ya_check_reciprocal": (C.c_long, [C.c_uint, C.c_uint]),
     "ya_sim_profile": (C.c_int, [_sim, C.c_int]),
     "ya_sim_profile_read": (C.c_int, [_sim, C.POINTER(C.c_double), _pi]),
 }
