@@ -464,11 +464,11 @@ __global__ __launch_bounds__(FORCE_BLOCK) void grid_force(const int n,
 
     // LDS (address space 3) FIFO pointers: 32-bit address arithmetic in the hot loops
     using Lds_u16 = __attribute__((address_space(3))) unsigned char;
-    Lds_u16* const q_base = (Lds_u16*)sh_q + threadIdx.x;          // this lane's FIFO, stride 256
+    Lds_u16* const q_base = (Lds_u16*)sh_q + threadIdx.x * QUEUE_DEPTH;  // this lane's FIFO
 #ifndef YA_GROUP
 #define YA_GROUP 4
 #endif
-    Lds_u16* const q_high = q_base + (QUEUE_DEPTH - YA_GROUP) * FORCE_BLOCK;  // "nearly full" mark
+    Lds_u16* const q_high = q_base + (QUEUE_DEPTH - YA_GROUP);  // "nearly full" mark
 
 #ifdef YA_NO_XCD_MAPPING
     const int s0 = blockIdx.x * FORCE_BLOCK;
@@ -539,7 +539,7 @@ __global__ __launch_bounds__(FORCE_BLOCK) void grid_force(const int n,
             // in flight together), until done or its FIFO is nearly full; when every
             // lane is done the wavefront moves to the next row; phase 2 drains the
             // FIFOs when a lane is full or the plane is finished.
-            Lds_u16* const q_last = q_base + (QUEUE_DEPTH - 1) * FORCE_BLOCK;
+            Lds_u16* const q_last = q_base + (QUEUE_DEPTH - 1);
             int row = 0;
             int t = max(k_begin[0] - wg_begin[0], chunk) - chunk;
             int b = min(k_end[0] - wg_begin[0], chunk + chunk_n) - chunk;
@@ -558,12 +558,12 @@ __global__ __launch_bounds__(FORCE_BLOCK) void grid_force(const int n,
                         d2[u] = dist2_to(Xi, w[u]);
                         keep_wide(w[u]);
                     }
+                    // the byte is always written and only kept (tail advanced) on a hit:
+                    // no branch, no exec masking
 #pragma unroll
                     for (int u = 0; u < YA_GROUP; u++) {
-                        if (d2[u] < cut2) {
-                            *q_tail = (unsigned char)((row << 6) + off + u);
-                            q_tail += FORCE_BLOCK;
-                        }
+                        *q_tail = (unsigned char)((row << 6) + off + u);
+                        q_tail += d2[u] < cut2;
                     }
                     t += YA_GROUP;
                     off += YA_GROUP;
@@ -572,10 +572,8 @@ __global__ __launch_bounds__(FORCE_BLOCK) void grid_force(const int n,
                        (t + YA_GROUP > b || q_tail > q_high || off + YA_GROUP > 64)) {
                     const float4 w = staged_words(&sh_e[t]);
                     keep_wide(w);
-                    if (dist2_to(Xi, w) < cut2) {
-                        *q_tail = (unsigned char)((row << 6) + off);
-                        q_tail += FORCE_BLOCK;
-                    }
+                    *q_tail = (unsigned char)((row << 6) + off);
+                    q_tail += dist2_to(Xi, w) < cut2;
                     t++;
                     off++;
                 }
@@ -600,13 +598,13 @@ __global__ __launch_bounds__(FORCE_BLOCK) void grid_force(const int n,
                 }
                 {  // phase 2: drain this lane's FIFO (no lambda: nothing may have its address
                    // taken here, the byte stores of phase 1 could alias it)
-                const int count = (int)(q_tail - q_base) / FORCE_BLOCK;
+                const int count = (int)(q_tail - q_base);
                 q_tail = q_base;
                 asm volatile("" : "+v"(q_tail));  // keep the tail an address, not base + count
                 int e_next = q_base[0];  // read one hit ahead: one LDS latency per trip, not two
                 for (int q = 0; q < count; q++) {
                     const int e = e_next;
-                    e_next = q_base[min(q + 1, QUEUE_DEPTH - 1) * FORCE_BLOCK];
+                    e_next = q_base[min(q + 1, QUEUE_DEPTH - 1)];
                     const int t = (e & 63) + (e >= 128 ? anchor2 : (e >= 64 ? anchor1 : anchor0));
                     const Entry<Pt> other = sh_e[t];
                     const unsigned slot = (e & 63) + (e >= 128 ? slot2 : (e >= 64 ? slot1 : slot0));

@@ -21,7 +21,7 @@ ln -s "$ROOT/include" "$TREE/include"
 for f in "$REF"/tests/*; do ln -s "$f" "$TREE/tests/"; done
 cd "$TREE/tests"
 for t in test_dtypes test_solvers test_links test_inits test_vtk; do
-  /opt/rocm/bin/hipcc -x hip --offload-arch=gfx950 -std=c++17 -O2 -ffp-contract=off \
+  /opt/rocm/bin/hipcc -x hip --offload-arch=gfx950 -std=c++17 -O2 -ffp-contract=off -fno-slp-vectorize \
       -Wno-error=parentheses -w -include "$ROOT/include/compat/cuda_names.h" -I"$ROOT/include/compat" \
       $t.cu -L"$ROOT/yalla_amd" -lyalla_hip -Wl,-rpath,'$ORIGIN/../../yalla_amd' -o "$OUT/$t"
   echo "built oracle/_ref/$t"
