@@ -9,6 +9,6 @@ for p in glob.glob(sys.argv[1]):
 out = {"grid_force_1M_springs": {"FETCH_SIZE_KiB": sum(agg['FETCH_SIZE'])/len(agg['FETCH_SIZE']),
                                  "WRITE_SIZE_KiB": sum(agg['WRITE_SIZE'])/len(agg['WRITE_SIZE']),
                                  "launches": len(agg['FETCH_SIZE']),
-                                 "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline"}}
+                                 "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline (tools/gpu_profile_round.sh)"}}
 json.dump(out, open(sys.argv[2], 'w'), indent=1)
 print(out)
