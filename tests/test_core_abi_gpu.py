@@ -67,6 +67,8 @@ def numpy_grid(X, cs, gs):
     sorted_ids = ids[order]
     start = np.full(gs ** 3, -1, np.int32)
     end = np.full(gs ** 3, -2, np.int32)
+    if len(ids) == 0:
+        return sorted_ids, order, start, end
     first = np.r_[True, sorted_ids[1:] != sorted_ids[:-1]]
     last = np.r_[sorted_ids[1:] != sorted_ids[:-1], True]
     start[sorted_ids[first]] = np.nonzero(first)[0]
@@ -105,6 +107,29 @@ def test_grid_build_is_bit_exact(hip, n, stride_f, gs, cs):
         assert np.array_equal(o, np.r_[0, np.cumsum(counts)].astype(np.int32))
     bits = C.c_int(-1)
     assert hip.ya_grid_status(g, C.byref(bits), 0) == 0 and bits.value == 0
+    hip.ya_grid_destroy(g)
+
+
+def test_grid_build_with_changing_population(hip):
+    """The visit order of a build comes from the previous build; the population may shrink
+    (a slab's ghost layer), grow (proliferation) or collapse in between."""
+    n_max, gs, cs, stride_f = 30000, 32, 1.0, 3
+    rng = np.random.default_rng(5)
+    X = ((rng.random((n_max, 3), dtype=np.float32) - 0.5) * np.float32(gs - 3)).astype(np.float32)
+    dX = Dev(hip, X)
+    g = C.c_void_p()
+    assert hip.ya_grid_create(n_max, gs, C.byref(g)) == 0
+    ptrs = [C.c_void_p() for _ in range(4)]
+    hip.ya_grid_arrays(g, *[C.byref(p) for p in ptrs])
+    for n in (20000, 19990, 19000, 30000, 29999, 12000, 500, 777, 0, 30000):
+        assert hip.ya_grid_build(g, dX.p, stride_f * 4, n, cs, None) == 0
+        hip.ya_device_synchronize()
+        ref = numpy_grid(X[:n], cs, gs)
+        for name, a, p, count in zip(("cube_id", "point_id", "cube_start", "cube_end"), ref, ptrs,
+                                     (n, n, gs ** 3, gs ** 3)):
+            out = np.empty(count, np.int32)
+            hip.ya_memcpy_d2h(out.ctypes.data, p, out.nbytes)
+            assert np.array_equal(a, out), (name, n)
     hip.ya_grid_destroy(g)
 
 

@@ -51,13 +51,15 @@ __device__ __forceinline__ int cube_id_of(float x, float y, float z, float cs, i
     return (int)((fx + fy) + fz);
 }
 
-// Visit order: position s of the previous build's sorted order, identity for
-// cells added since (ids >= n_prev).  A bijection on [0, n) whenever prev_pid is
-// a permutation of [0, n_prev) and n >= n_prev; the host passes n_prev = 0
-// otherwise.
-__device__ __forceinline__ int visit(int s, const int* __restrict__ prev_pid, int n_prev)
+// Visit order over max(n, n_prev) positions: position s of the previous build's
+// sorted order, identity for cells added since (ids >= n_prev); -1 where the
+// previous build held a cell that no longer exists (id >= n: the population
+// shrank, e.g. a slab's ghost layer).  prev_pid is a permutation of [0, n_prev), so
+// every id in [0, n) is visited exactly once.
+__device__ __forceinline__ int visit(int s, const int* __restrict__ prev_pid, int n_prev, int n)
 {
-    return s < n_prev ? prev_pid[s] : s;
+    const int i = s < n_prev ? prev_pid[s] : s;
+    return i < n ? i : -1;
 }
 
 __global__ __launch_bounds__(BLOCK) void k_bin(const float* __restrict__ X,
@@ -66,9 +68,10 @@ __global__ __launch_bounds__(BLOCK) void k_bin(const float* __restrict__ X,
     int* __restrict__ status)
 {
     int s = blockIdx.x * BLOCK + threadIdx.x;
+    const int n_visit = max(n, n_prev);
     int id = -1;
-    if (s < n) {
-        int i = visit(s, prev_pid, n_prev);
+    const int i = s < n_visit ? visit(s, prev_pid, n_prev, n) : -1;
+    if (i >= 0) {
         const float* p = X + (size_t)i * stride_f;
         id = cube_id_of(p[0], p[1], p[2], cs, gs);
         if (id < 0 || id >= n_cubes) {
@@ -91,8 +94,8 @@ __global__ __launch_bounds__(BLOCK) void k_bin(const float* __restrict__ X,
     int base = 0;
     if (head && id >= 0) base = atomicAdd(&count[id], run_end - lane);
     base = __shfl(base, head_lane, 64);
-    if (s < n) {
-        cube_of[s] = id;
+    if (s < n_visit) {
+        cube_of[s] = id;  // -1: nothing to visit at this position
         rank[s] = base + (lane - head_lane);
     }
 }
@@ -180,10 +183,11 @@ __global__ __launch_bounds__(BLOCK) void k_scatter(const int* __restrict__ cube_
     int* __restrict__ cube_id_sorted)
 {
     int s = blockIdx.x * BLOCK + threadIdx.x;
-    if (s >= n) return;
+    if (s >= max(n, n_prev)) return;
     int c = cube_of[s];
+    if (c < 0) return;
     int slot = offs[c] + rank[s];
-    arrival_pid[slot] = visit(s, prev_pid, n_prev);
+    arrival_pid[slot] = visit(s, prev_pid, n_prev, n);
     cube_id_sorted[slot] = c;
 }
 
@@ -525,16 +529,18 @@ int ya_grid_build_sorted(ya_grid* g, const void* d_X, size_t stride_bytes,
     hipStream_t st = (hipStream_t)stream;
     const int stride_f = (int)(stride_bytes / 4);
     const int nb = ceil_div(n, BLOCK);
-    const int n_prev = n >= g->n_prev ? g->n_prev : 0;
+    // the previous order is worth visiting unless the population collapsed
+    const int n_prev = g->n_prev <= 2 * (long)n ? g->n_prev : 0;
+    const int nb_visit = ceil_div(n > n_prev ? n : n_prev, BLOCK);
     if (n > 0)
-        k_bin<<<nb, BLOCK, 0, st>>>((const float*)d_X, stride_f, n, cube_size, g->grid_size,
+        k_bin<<<nb_visit, BLOCK, 0, st>>>((const float*)d_X, stride_f, n, cube_size, g->grid_size,
             g->n_cubes, g->d_prev_pid, n_prev, g->d_cube_of, g->d_rank, g->d_count, g->d_status);
     k_tile_sum<<<g->n_tiles, BLOCK, 0, st>>>(g->d_count, g->d_tile_sums);
     k_scan<<<g->n_tiles, BLOCK, 0, st>>>(g->d_count, g->d_tile_sums, g->n_cubes, n, g->d_offs,
         g->d_cube_start, g->d_cube_end);
     if (n > 0) {
-        k_scatter<<<nb, BLOCK, 0, st>>>(g->d_cube_of, g->d_rank, g->d_offs, n, g->d_prev_pid,
-            n_prev, g->d_arrival, g->d_cube_id);
+        k_scatter<<<nb_visit, BLOCK, 0, st>>>(g->d_cube_of, g->d_rank, g->d_offs, n,
+            g->d_prev_pid, n_prev, g->d_arrival, g->d_cube_id);
         const bool gather = d_sorted_X != nullptr;
         if (gather && (entry_bytes < stride_bytes + 4 || entry_bytes % 4 || !d_sorted_v || !d_old_v))
             return (int)hipErrorInvalidValue;
