@@ -47,6 +47,7 @@ inline void gather_rows(const void* src, size_t row_bytes, const int* idx, const
 }
 inline void copy(void* dst, const void* src, size_t bytes) { memmove(dst, src, bytes); }
 inline int read_int(const void* d) { return *(const int*)d; }
+inline void read_ints(const void* d, int k, int* out) { memcpy(out, d, (size_t)k * sizeof(int)); }
 inline void write_int(void* d, int v) { *(int*)d = v; }
 inline void mean_from_total(const float* total, int n_floats, float* fix)
 {

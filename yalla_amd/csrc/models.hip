@@ -55,6 +55,10 @@ inline int read_int(const void* d)
     YA_CHECK(ya_memcpy_d2h(&v, d, sizeof(int)));
     return v;
 }
+inline void read_ints(const void* d, int k, int* out)
+{
+    YA_CHECK(ya_memcpy_d2h(out, d, (size_t)k * sizeof(int)));
+}
 inline void write_int(void* d, int v) { YA_CHECK(ya_memcpy_h2d(d, &v, sizeof(int))); }
 __global__ void k_mean_from_total(const float* total, int n_floats, float* fix)
 {
