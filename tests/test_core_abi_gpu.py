@@ -25,6 +25,8 @@ def hip():
     lib.ya_grid_offsets.argtypes = [vp, C.POINTER(vp)]
     lib.ya_grid_build.argtypes = [vp, vp, sz, i32, f32, vp]
     lib.ya_grid_status.argtypes = [vp, C.POINTER(i32), i32]
+    lib.ya_grid_build_sorted.argtypes = [vp, vp, sz, vp, i32, f32, vp, sz, vp, vp]
+    lib.ya_grid_rebuild_sorted.argtypes = [vp, vp, sz, sz, vp, i32, f32, vp, vp, vp]
     lib.ya_select_z.argtypes = [vp, sz, i32, f32, f32, vp, vp, vp, vp]
     lib.ya_select_workspace_bytes.restype = sz
     lib.ya_select_workspace_bytes.argtypes = [i32]
@@ -130,6 +132,60 @@ def test_grid_build_with_changing_population(hip):
             out = np.empty(count, np.int32)
             hip.ya_memcpy_d2h(out.ctypes.data, p, out.nbytes)
             assert np.array_equal(a, out), (name, n)
+    hip.ya_grid_destroy(g)
+
+
+@pytest.mark.parametrize("point_f,entry_f", [(3, 4), (4, 8), (5, 6)])
+def test_rebuild_from_sorted_cells_equals_build_from_original_order(hip, point_f, entry_f):
+    """ya_grid_rebuild_sorted (second Heun stage): cells that sit in an earlier build's
+    sorted arrays and have moved since give exactly the arrays a build from the
+    original-order arrays gives -- public arrays, sorted entries and sorted old_v."""
+    n, gs, cs = 40000, 32, 1.0
+    rng = np.random.default_rng(point_f)
+    X = np.zeros((n, point_f), np.float32)
+    X[:, :3] = (rng.random((n, 3), dtype=np.float32) - 0.5) * np.float32(gs - 4)
+    X[:, 3:] = rng.random((n, point_f - 3), dtype=np.float32)
+    V = rng.random((n, 3), dtype=np.float32)
+    g = C.c_void_p()
+    assert hip.ya_grid_create(n, gs, C.byref(g)) == 0
+    ptrs = [C.c_void_p() for _ in range(4)]
+    hip.ya_grid_arrays(g, *[C.byref(p) for p in ptrs])
+    dV = Dev(hip, V)
+    first, first_v = Dev(hip, nbytes=n * entry_f * 4), Dev(hip, nbytes=n * 16)
+    assert hip.ya_grid_build_sorted(g, Dev(hip, X).p, point_f * 4, dV.p, n, cs, first.p, entry_f * 4,
+                                    first_v.p, None) == 0
+    entries = first.get(np.float32, n * entry_f).reshape(n, entry_f)
+    ids = entries[:, point_f].view(np.int32)
+    assert np.array_equal(np.sort(ids), np.arange(n))
+    # the cells move (a predictor step); the sorted copy is updated in place
+    X2 = X.copy()
+    X2[:, :3] += (rng.random((n, 3), dtype=np.float32) - 0.5) * np.float32(0.8)
+    entries[:, :point_f] = X2[ids]
+    moved = Dev(hip, entries)
+    out, out_v = Dev(hip, nbytes=n * entry_f * 4), Dev(hip, nbytes=n * 16)
+    assert hip.ya_grid_rebuild_sorted(g, moved.p, entry_f * 4, point_f * 4, first_v.p, n, cs, out.p,
+                                      out_v.p, None) == 0
+    hip.ya_device_synchronize()
+    got = []
+    for p, count in zip(ptrs, (n, n, gs ** 3, gs ** 3)):
+        a = np.empty(count, np.int32)
+        hip.ya_memcpy_d2h(a.ctypes.data, p, a.nbytes)
+        got.append(a)
+    got_entries = out.get(np.float32, n * entry_f).reshape(n, entry_f)
+    got_v = out_v.get(np.float32, n * 4).reshape(n, 4)
+    # reference: a build from the original-order arrays
+    want, want_v = Dev(hip, nbytes=n * entry_f * 4), Dev(hip, nbytes=n * 16)
+    assert hip.ya_grid_build_sorted(g, Dev(hip, X2).p, point_f * 4, dV.p, n, cs, want.p, entry_f * 4,
+                                    want_v.p, None) == 0
+    hip.ya_device_synchronize()
+    ref = numpy_grid(X2, cs, gs)
+    for name, a, b in zip(("cube_id", "point_id", "cube_start", "cube_end"), ref, got):
+        assert np.array_equal(a, b), name
+    want_entries = want.get(np.float32, n * entry_f).reshape(n, entry_f)
+    assert np.array_equal(got_entries[:, :point_f + 1].view(np.uint32),
+                          want_entries[:, :point_f + 1].view(np.uint32))
+    assert np.array_equal(got_v[:, :3], want_v.get(np.float32, n * 4).reshape(n, 4)[:, :3])
+    assert np.array_equal(got_v[:, :3], V[ref[1]])
     hip.ya_grid_destroy(g)
 
 
