@@ -65,7 +65,7 @@ __device__ __forceinline__ int visit(int s, const int* __restrict__ prev_pid, in
 __global__ __launch_bounds__(BLOCK) void k_bin(const float* __restrict__ X,
     int stride_f, int n, float cs, int gs, int n_cubes, const int* __restrict__ prev_pid,
     int n_prev, int* __restrict__ cube_of, int* __restrict__ rank, int* __restrict__ count,
-    int* __restrict__ status)
+    int* __restrict__ status, float* __restrict__ stash, int stash_f)
 {
     int s = blockIdx.x * BLOCK + threadIdx.x;
     const int n_visit = max(n, n_prev);
@@ -73,7 +73,17 @@ __global__ __launch_bounds__(BLOCK) void k_bin(const float* __restrict__ X,
     const int i = s < n_visit ? visit(s, prev_pid, n_prev, n) : -1;
     if (i >= 0) {
         const float* p = X + (size_t)i * stride_f;
-        id = cube_id_of(p[0], p[1], p[2], cs, gs);
+        const float x = p[0], y = p[1], z = p[2];
+        // the point, kept in visit order for k_order (which then reads it nearly
+        // in sequence instead of gathering it by id a second time)
+        if (stash) {
+            float* out = stash + (size_t)s * stash_f;
+            out[0] = x;
+            out[1] = y;
+            out[2] = z;
+            for (int k = 3; k < stash_f; k++) out[k] = p[k];
+        }
+        id = cube_id_of(x, y, z, cs, gs);
         if (id < 0 || id >= n_cubes) {
             atomicOr(status, YA_STATUS_OUT_OF_GRID);
             id = id < 0 ? 0 : n_cubes - 1;
@@ -180,7 +190,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan(int* __restrict__ count,
 __global__ __launch_bounds__(BLOCK) void k_scatter(const int* __restrict__ cube_of,
     const int* __restrict__ rank, const int* __restrict__ offs, int n,
     const int* __restrict__ prev_pid, int n_prev, int* __restrict__ arrival_pid,
-    int* __restrict__ cube_id_sorted)
+    int* __restrict__ cube_id_sorted, int* __restrict__ arrival_src)
 {
     int s = blockIdx.x * BLOCK + threadIdx.x;
     if (s >= max(n, n_prev)) return;
@@ -189,6 +199,7 @@ __global__ __launch_bounds__(BLOCK) void k_scatter(const int* __restrict__ cube_
     int slot = offs[c] + rank[s];
     arrival_pid[slot] = visit(s, prev_pid, n_prev, n);
     cube_id_sorted[slot] = c;
+    if (arrival_src) arrival_src[slot] = s;
 }
 
 // Rank-count inside the cube's segment: slot of point p = segment start +
@@ -199,7 +210,8 @@ __global__ __launch_bounds__(BLOCK) void k_order(const int* __restrict__ arrival
     const int* __restrict__ cube_id_sorted, const int* __restrict__ offs, int n,
     int* __restrict__ point_id, int* __restrict__ next_prev_pid, const float* __restrict__ X,
     int stride_f, const float* __restrict__ old_v, float* __restrict__ sorted_X, int entry_f,
-    float4* __restrict__ sorted_v)
+    float4* __restrict__ sorted_v, const float* __restrict__ stash,
+    const int* __restrict__ arrival_src)
 {
     int s = blockIdx.x * BLOCK + threadIdx.x;
     if (s >= n) return;
@@ -212,7 +224,8 @@ __global__ __launch_bounds__(BLOCK) void k_order(const int* __restrict__ arrival
     point_id[dst] = p;
     next_prev_pid[dst] = p;
     if (NW > 0) {
-        const float* src = X + (size_t)p * stride_f;
+        const float* src =
+            stash ? stash + (size_t)arrival_src[s] * NW : X + (size_t)p * stride_f;
         float* out = sorted_X + (size_t)dst * entry_f;
         float v[NW > 0 ? NW : 1];
 #pragma unroll
@@ -410,6 +423,9 @@ struct ya_grid {
     int *d_cube_id, *d_point_id, *d_cube_start, *d_cube_end;  // public
     int *d_offs, *d_count, *d_tile_sums;                      // private
     int *d_cube_of, *d_rank, *d_arrival;                      // private, [n_max]
+    int *d_arrival_src;  // visit position of the cell that arrived in a slot
+    float* d_stash;      // the points in visit order (ya_grid_build_sorted), lazily sized
+    size_t stash_bytes;
     int *d_prev_pid;  // private copy of the last build's point ids (visit order)
     int n_prev;       // cells in that build; 0 = none / unusable
     int* d_status;
@@ -468,6 +484,7 @@ int ya_grid_create(int n_max, int grid_size, ya_grid** out)
     YA_TRY(hipMalloc(&g->d_cube_of, nb));
     YA_TRY(hipMalloc(&g->d_rank, nb));
     YA_TRY(hipMalloc(&g->d_arrival, nb));
+    YA_TRY(hipMalloc(&g->d_arrival_src, nb));
     YA_TRY(hipMalloc(&g->d_prev_pid, nb));
     YA_TRY(hipMalloc(&g->d_cube_start, cb));
     YA_TRY(hipMalloc(&g->d_cube_end, cb));
@@ -492,6 +509,8 @@ int ya_grid_destroy(ya_grid* g)
     (void)hipFree(g->d_cube_of);
     (void)hipFree(g->d_rank);
     (void)hipFree(g->d_arrival);
+    (void)hipFree(g->d_arrival_src);
+    (void)hipFree(g->d_stash);
     (void)hipFree(g->d_prev_pid);
     (void)hipFree(g->d_cube_start);
     (void)hipFree(g->d_cube_end);
@@ -531,17 +550,31 @@ int ya_grid_build_sorted(ya_grid* g, const void* d_X, size_t stride_bytes,
     const int nb = ceil_div(n, BLOCK);
     // the previous order is worth visiting unless the population collapsed
     const int n_prev = g->n_prev <= 2 * (long)n ? g->n_prev : 0;
-    const int nb_visit = ceil_div(n > n_prev ? n : n_prev, BLOCK);
+    const int n_visit = n > n_prev ? n : n_prev;
+    const int nb_visit = ceil_div(n_visit, BLOCK);
+    const bool gather = d_sorted_X != nullptr;
+    float* stash = nullptr;
+    if (gather && n > 0) {  // the stash grows with the first use (and with a wider point)
+        const size_t need = (size_t)g->n_max * stride_bytes;
+        if (g->stash_bytes < need) {
+            (void)hipFree(g->d_stash);
+            g->d_stash = nullptr;
+            g->stash_bytes = 0;
+            YA_TRY(hipMalloc(&g->d_stash, need));
+            g->stash_bytes = need;
+        }
+        stash = g->d_stash;
+    }
     if (n > 0)
         k_bin<<<nb_visit, BLOCK, 0, st>>>((const float*)d_X, stride_f, n, cube_size, g->grid_size,
-            g->n_cubes, g->d_prev_pid, n_prev, g->d_cube_of, g->d_rank, g->d_count, g->d_status);
+            g->n_cubes, g->d_prev_pid, n_prev, g->d_cube_of, g->d_rank, g->d_count, g->d_status,
+            stash, stride_f);
     k_tile_sum<<<g->n_tiles, BLOCK, 0, st>>>(g->d_count, g->d_tile_sums);
     k_scan<<<g->n_tiles, BLOCK, 0, st>>>(g->d_count, g->d_tile_sums, g->n_cubes, n, g->d_offs,
         g->d_cube_start, g->d_cube_end);
     if (n > 0) {
         k_scatter<<<nb_visit, BLOCK, 0, st>>>(g->d_cube_of, g->d_rank, g->d_offs, n,
-            g->d_prev_pid, n_prev, g->d_arrival, g->d_cube_id);
-        const bool gather = d_sorted_X != nullptr;
+            g->d_prev_pid, n_prev, g->d_arrival, g->d_cube_id, stash ? g->d_arrival_src : nullptr);
         if (gather && (entry_bytes < stride_bytes + 4 || entry_bytes % 4 || !d_sorted_v || !d_old_v))
             return (int)hipErrorInvalidValue;
         const int entry_f = (int)(entry_bytes / 4);
@@ -549,7 +582,7 @@ int ya_grid_build_sorted(ya_grid* g, const void* d_X, size_t stride_bytes,
     case NW:                                                                             \
         k_order<NW><<<nb, BLOCK, 0, st>>>(g->d_arrival, g->d_cube_id, g->d_offs, n,      \
             g->d_point_id, g->d_prev_pid, (const float*)d_X, stride_f, (const float*)d_old_v, \
-            (float*)d_sorted_X, entry_f, (float4*)d_sorted_v);                           \
+            (float*)d_sorted_X, entry_f, (float4*)d_sorted_v, stash, g->d_arrival_src);  \
         break;
         switch (gather ? stride_f : 0) {
             YA_ORDER(0)
@@ -590,13 +623,14 @@ int ya_grid_rebuild_sorted(ya_grid* g, const void* d_prev_sorted, size_t entry_b
     // cells are read in the order they are stored: visit = identity (n_prev = 0)
     if (n > 0)
         k_bin<<<nb, BLOCK, 0, st>>>((const float*)d_prev_sorted, entry_f, n, cube_size, g->grid_size,
-            g->n_cubes, g->d_prev_pid, 0, g->d_cube_of, g->d_rank, g->d_count, g->d_status);
+            g->n_cubes, g->d_prev_pid, 0, g->d_cube_of, g->d_rank, g->d_count, g->d_status,
+            nullptr, 0);
     k_tile_sum<<<g->n_tiles, BLOCK, 0, st>>>(g->d_count, g->d_tile_sums);
     k_scan<<<g->n_tiles, BLOCK, 0, st>>>(g->d_count, g->d_tile_sums, g->n_cubes, n, g->d_offs,
         g->d_cube_start, g->d_cube_end);
     if (n > 0) {
         k_scatter<<<nb, BLOCK, 0, st>>>(g->d_cube_of, g->d_rank, g->d_offs, n, g->d_prev_pid, 0,
-            g->d_arrival, g->d_cube_id);
+            g->d_arrival, g->d_cube_id, nullptr);
         const int id_word = (int)(point_bytes / 4);
 #define YA_ORDER_FROM(EW)                                                                    \
     case EW:                                                                                 \
