@@ -805,10 +805,11 @@ __global__ __launch_bounds__(ya::UPDATE_BLOCK) void heun_step(const int n, const
 template<typename Pt>
 __global__ __launch_bounds__(ya::UPDATE_BLOCK) void euler_step_sorted(const int n, const float dt,
     const float* __restrict__ d_fix, const Pt* __restrict__ d_dX_sorted,
-    ya::Entry<Pt>* __restrict__ d_sorted)
+    ya::Entry<Pt>* __restrict__ d_sorted, const int n_active)
 {
     const int s = blockIdx.x * ya::UPDATE_BLOCK + threadIdx.x;
     if (s >= n) return;
+    if (d_sorted[s].id >= n_active) return;  // a ghost cell: moved by its owner
 
     Pt dX = d_dX_sorted[s];
     dX.x -= d_fix[0];
@@ -817,6 +818,19 @@ __global__ __launch_bounds__(ya::UPDATE_BLOCK) void euler_step_sorted(const int 
     ya::Entry<Pt> e = d_sorted[s];
     e.X = e.X + dX * dt;
     d_sorted[s] = e;
+}
+
+// z-slab decomposition: the ghost cells' predictor positions arrive from the slab
+// neighbours in original order (d_X1[id], id >= n_active) and are put into the sorted
+// copy here; the own cells were moved by euler_step_sorted.
+template<typename Pt>
+__global__ __launch_bounds__(ya::UPDATE_BLOCK) void ghosts_into_sorted(const int n,
+    const int n_active, const Pt* __restrict__ d_X1, ya::Entry<Pt>* __restrict__ d_sorted)
+{
+    const int s = blockIdx.x * ya::UPDATE_BLOCK + threadIdx.x;
+    if (s >= n) return;
+    const int id = d_sorted[s].id;
+    if (id >= n_active) d_sorted[s].X = d_X1[id];
 }
 
 template<typename Pt>
@@ -968,6 +982,7 @@ protected:
     float3* d_old_v;
     int* d_n;
     float *d_mean, *d_fix, *d_mean_first, *d_fix_first, *d_workspace;
+    int sorted_stage_cells = -1;  // stage API: cells in the sorted copy stage 2 may start from
     bool fix_com = true;
     bool fix_com_z = false;
     int fix_point = 0;
@@ -1006,12 +1021,23 @@ protected:
         Pt* d_in = stage == 1 ? d_X : d_X1;
         Pt* d_rhs = stage == 1 ? d_dX : d_dX1;
         const bool has_gen = !ya::is_no_gen_forces<Pt>(gen_forces);
+        if (stage == 2 && sorted_stage_cells == n && !has_gen) {
+            // sorted-space second stage (see take_step): the own cells were moved by
+            // stage_update(1), the ghost cells' new positions are in d_X1
+            sorted_stage_cells = -1;
+            Computer<Pt>::ghosts_in_sorted_space(n, n_active, d_X1);
+            Computer<Pt>::template pwints_from_sorted<pw_int, pw_friction>(n, d_dX1, n_active);
+            return;
+        }
+        sorted_stage_cells = -1;
         if (has_gen) {
             YA_CHECK(ya_memset_async(d_rhs, 0, (size_t)n * sizeof(Pt), nullptr));
             gen_forces(n, d_in, d_rhs);
         }
+        const bool keep_sorted = stage == 1 && !has_gen && Computer<Pt>::use_sorted_pipeline();
         Computer<Pt>::template pwints<pw_int, pw_friction>(
-            n, d_in, d_old_v, d_rhs, has_gen, n_active, false);
+            n, d_in, d_old_v, d_rhs, has_gen, n_active, keep_sorted);
+        if (keep_sorted) sorted_stage_cells = n;
     }
     // sum and mean of the stage's right-hand side over the first n points, left on
     // the device as {mean[n_floats], sum[n_floats]}
@@ -1024,9 +1050,13 @@ protected:
     void stage_update(int stage, int n, float dt, const float* d_fix_velocity)
     {
         const int blocks = (n + ya::UPDATE_BLOCK - 1) / ya::UPDATE_BLOCK;
-        if (stage == 1)
+        if (stage == 1) {
+            // before euler_step: it replaces d_dX by d_dX - fix, the sorted copy is raw
+            if (sorted_stage_cells >= 0)
+                Computer<Pt>::predictor_in_sorted_space(
+                    sorted_stage_cells, dt, d_fix_velocity, n);
             euler_step<<<blocks, ya::UPDATE_BLOCK>>>(n, dt, d_X, d_fix_velocity, d_dX, d_X1);
-        else
+        } else
             heun_step<<<blocks, ya::UPDATE_BLOCK>>>(
                 n, dt, d_dX, d_fix_velocity, d_dX1, d_X, d_old_v);
     }
@@ -1045,8 +1075,8 @@ protected:
             Computer<Pt>::template pwints<pw_int, pw_friction>(n, d_X, d_old_v, d_dX, false, n, true);
             // this stage's fixed velocity has to outlive the next reduction
             const float* fix = fix_velocity(n, d_dX, fix_com or fix_com_z, fix_com_z, true);
-            Computer<Pt>::predictor_in_sorted_space(n, dt, fix);
-            Computer<Pt>::template pwints_from_sorted<pw_int, pw_friction>(n, d_dX1);
+            Computer<Pt>::predictor_in_sorted_space(n, dt, fix, n);
+            Computer<Pt>::template pwints_from_sorted<pw_int, pw_friction>(n, d_dX1, n);
             const float* fix1 = fix_velocity(n, d_dX1, fix_com, false);
             heun_step_raw<<<blocks, ya::UPDATE_BLOCK>>>(
                 n, dt, d_dX, fix, d_dX1, fix1, d_X, d_old_v);
@@ -1077,9 +1107,10 @@ public:
 
 protected:
     void check_status() {}
-    void predictor_in_sorted_space(int, float, const float*) {}
+    void predictor_in_sorted_space(int, float, const float*, int) {}
+    void ghosts_in_sorted_space(int, int, const Pt*) {}
     template<Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction>
-    void pwints_from_sorted(int, Pt*) {}
+    void pwints_from_sorted(int, Pt*, int) {}
     template<Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction>
     void pwints(const int n, const Pt* __restrict__ d_X, const float3* __restrict__ d_old_v,
         Pt* d_dX, const bool has_gen, const int n_active, const bool keep_sorted)
@@ -1242,16 +1273,23 @@ protected:
     }
     // The two halves of the second Heun stage when the first one kept its
     // right-hand side in cell order (Heun_solver::take_step).
-    void predictor_in_sorted_space(const int n, const float dt, const float* d_fix)
+    void predictor_in_sorted_space(
+        const int n, const float dt, const float* d_fix, const int n_active)
     {
         euler_step_sorted<<<(n + ya::UPDATE_BLOCK - 1) / ya::UPDATE_BLOCK, ya::UPDATE_BLOCK>>>(
-            n, dt, d_fix, d_dX_sorted, d_sorted);
+            n, dt, d_fix, d_dX_sorted, d_sorted, n_active);
+    }
+    void ghosts_in_sorted_space(const int n, const int n_active, const Pt* d_X1)
+    {
+        if (n_active >= n) return;
+        ghosts_into_sorted<<<(n + ya::UPDATE_BLOCK - 1) / ya::UPDATE_BLOCK, ya::UPDATE_BLOCK>>>(
+            n, n_active, d_X1, d_sorted);
     }
     template<Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction>
-    void pwints_from_sorted(const int n, Pt* d_dX)
+    void pwints_from_sorted(const int n, Pt* d_dX, const int n_active)
     {
         grid.rebuild_sorted(n, d_sorted, d_sorted_v, cube_size, d_resorted, d_resorted_v);
-        forces<pw_int, pw_friction>(n, d_resorted, d_resorted_v, d_dX, false, n, nullptr);
+        forces<pw_int, pw_friction>(n, d_resorted, d_resorted_v, d_dX, false, n_active, nullptr);
     }
 };
 
