@@ -39,7 +39,8 @@ def assert_close_positions(a, b):
     assert np.abs(a - b).max() <= REL_TOL * scale
 
 
-@pytest.mark.parametrize("n,gs,steps", [(50, 50, 3), (800, 50, 3), (4096, 50, 2), (20000, 64, 2)])
+@pytest.mark.parametrize("n,gs,steps", [(50, 50, 3), (800, 50, 3), (4096, 50, 2), (20000, 64, 2),
+                                        (150000, 64, 1)])
 def test_springs_grid_bit_exact(oracle, device, n, gs, steps):
     (Xo, vo, go), (Xd, vd, gd) = run_both(
         oracle, device, "springs_grid", n, gs, 1.0, 0.5, 42, 0.001, steps)
@@ -80,6 +81,25 @@ def test_direct_and_staged_force_kernels_agree(oracle, device):
         assert np.array_equal(Xo.view(np.uint32), Xd.view(np.uint32)), variant
         res.append(Xd)
     assert np.array_equal(res[0].view(np.uint32), res[1].view(np.uint32))
+
+
+def test_both_second_stage_pipelines_agree(oracle, device):
+    """The second Heun stage built from the cube-sorted cells (default) and from d_X1
+    (the reference's structure) are the same arithmetic: bit-identical positions,
+    velocities and grid arrays, for a 16-byte and a 24-byte point entry."""
+    for model, n, dt in (("springs_grid", 60000, 0.001), ("relu_po_grid", 20000, 0.1)):
+        res = []
+        for sorted_pipeline in (0, 1):
+            with Solution(model, n, 64, 1.0, lib=device) as s:
+                s.random_sphere(0.5, 11)
+                s.set_param("sorted_pipeline", sorted_pipeline)
+                s.take_step(dt, 3)
+                res.append((s.positions(), s.old_v(), s.grid()))
+        (Xa, va, ga), (Xb, vb, gb) = res
+        assert np.array_equal(Xa.view(np.uint32), Xb.view(np.uint32)), model
+        assert np.array_equal(va.view(np.uint32), vb.view(np.uint32)), model
+        for a, b in zip(ga, gb):
+            assert np.array_equal(a, b), model
 
 
 def test_device_kernels_really_ran(device):
