@@ -416,7 +416,8 @@ __device__ __forceinline__ float dist2(const Pt& a, const Pt& b)
 // Cells staged in LDS at a time (16 B per float3 cell) and the per-thread
 // hit-queue depth (one byte per queued hit): 928 * 16 B + 44 * 256 B = 26 KiB per
 // workgroup, i.e. six workgroups (24 wavefronts) per CU.  Swept on MI355X
-// (DESIGN.md §6): occupancy, not instruction count, is what limits this kernel.
+// (DESIGN.md §6): workgroup size, staging capacity and queue depth all sit at a
+// shallow optimum here.
 template<typename Pt>
 struct Stage_cells {
 #ifndef YA_STAGE_CELLS
@@ -440,8 +441,8 @@ constexpr int QUEUE_DEPTH = YA_QUEUE_DEPTH;
 // (coalesced 16-byte loads of {X, id}), then every thread
 //
 //   phase 1  walks its candidates in the reference's order testing d2 < cut2
-//            only, and appends the LDS index of each hit (~15 % of the 27-cube
-//            volume lies inside the cut-off sphere) to a per-thread FIFO in LDS;
+//            only, and appends one byte per hit (~15 % of the 27-cube volume lies
+//            inside the cut-off sphere) to a per-thread FIFO in LDS;
 //   phase 2  drains the FIFO: distance, functor, friction, old_v term.
 //
 // Both loops run until the slowest lane of the wavefront is done, so phase 2 is
@@ -463,12 +464,12 @@ __global__ __launch_bounds__(FORCE_BLOCK) void grid_force(const int n,
     __shared__ unsigned char sh_q[QUEUE_DEPTH * FORCE_BLOCK];
 
     // LDS (address space 3) FIFO pointers: 32-bit address arithmetic in the hot loops
-    using Lds_u16 = __attribute__((address_space(3))) unsigned char;
-    Lds_u16* const q_base = (Lds_u16*)sh_q + threadIdx.x * QUEUE_DEPTH;  // this lane's FIFO
+    using Lds_byte = __attribute__((address_space(3))) unsigned char;
+    Lds_byte* const q_base = (Lds_byte*)sh_q + threadIdx.x * QUEUE_DEPTH;  // this lane's FIFO
 #ifndef YA_GROUP
 #define YA_GROUP 4
 #endif
-    Lds_u16* const q_high = q_base + (QUEUE_DEPTH - YA_GROUP);  // "nearly full" mark
+    Lds_byte* const q_high = q_base + (QUEUE_DEPTH - YA_GROUP);  // "nearly full" mark
 
 #ifdef YA_NO_XCD_MAPPING
     const int s0 = blockIdx.x * FORCE_BLOCK;
@@ -493,7 +494,7 @@ __global__ __launch_bounds__(FORCE_BLOCK) void grid_force(const int n,
     Pt F = ya::zero<Pt>();
     float3 sum_v{0.f, 0.f, 0.f};
     float sum_friction = 0;
-    Lds_u16* q_tail = q_base;
+    Lds_byte* q_tail = q_base;
     asm volatile("" : "+v"(q_tail));
 
     // LDS index of a staged cell -> its slot in the sorted arrays (set per chunk):
@@ -539,7 +540,7 @@ __global__ __launch_bounds__(FORCE_BLOCK) void grid_force(const int n,
             // in flight together), until done or its FIFO is nearly full; when every
             // lane is done the wavefront moves to the next row; phase 2 drains the
             // FIFOs when a lane is full or the plane is finished.
-            Lds_u16* const q_last = q_base + (QUEUE_DEPTH - 1);
+            Lds_byte* const q_last = q_base + (QUEUE_DEPTH - 1);
             int row = 0;
             int t = max(k_begin[0] - wg_begin[0], chunk) - chunk;
             int b = min(k_end[0] - wg_begin[0], chunk + chunk_n) - chunk;
