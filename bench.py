@@ -193,8 +193,8 @@ def main():
         n_force = n
     else:
         slab_mod.step([my_slab], comm, dt, migrate=True)  # untimed: settle ownership, then count
-        n_force = my_slab.n_local   # own + ghost cells the last force launch saw
-        counts = torch.tensor([my_slab.n_own()], dtype=torch.int64, device="cuda")
+        n_force = my_slab.n_own()   # cells a force launch computes (ghost cells get none)
+        counts = torch.tensor([n_force], dtype=torch.int64, device="cuda")
         dist.all_reduce(counts)
         assert int(counts.item()) == n_total, "cells were lost or duplicated in migration"
 
