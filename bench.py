@@ -50,6 +50,10 @@ def parse():
                     help="use the z-slab path (ghost exchange + all-reduce) even on 1 GPU")
     ap.add_argument("--force-variant", type=int, default=1,
                     help="1 = LDS-staged grid_force (default), 0 = grid_force_direct (A/B)")
+    ap.add_argument("--backend", default="nccl",
+                    help="torch.distributed backend for N > 1 / --slab: nccl (= RCCL), or gloo with "
+                         "YALLA_BENCH_DEVICE=0 to rehearse the N-rank path on one GPU (RCCL refuses "
+                         "two ranks per GPU; messages are then staged through the host)")
     ap.add_argument("--time-every", type=int, default=5,
                     help="attach HIP events to every this-many-th force-kernel launch (odd: both stages)")
     ap.add_argument("--sorted-pipeline", type=int, default=1,
@@ -109,6 +113,8 @@ def main():
     os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "YALLA_BENCH_DEVICE" in os.environ:  # testing only: several ranks on one GPU
+        local_rank = int(os.environ["YALLA_BENCH_DEVICE"])
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
@@ -126,7 +132,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
 
     from yalla_amd.solution import Solution
 
@@ -194,11 +203,12 @@ def main():
     else:
         slab_mod.step([my_slab], comm, dt, migrate=True)  # untimed: settle ownership, then count
         n_force = my_slab.n_own()   # cells a force launch computes (ghost cells get none)
-        counts = torch.tensor([n_force], dtype=torch.int64, device="cuda")
+        counts = torch.tensor([n_force], dtype=torch.int64,
+                              device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(counts)
         assert int(counts.item()) == n_total, "cells were lost or duplicated in migration"
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -229,7 +239,9 @@ def main():
                 "grid_size": gs,
                 "cube_size": 1.0,
                 "parallelism": "1 GPU" if world == 1 else
-                               f"{world} z-slabs of one {n_total}-cell system, ghost exchange via RCCL send/recv",
+                               f"{world} z-slabs of one {n_total}-cell system, ghost exchange via "
+                               + ("RCCL send/recv" if args.backend == "nccl" else
+                                  f"{args.backend} send/recv staged through the host (rehearsal mode)"),
             },
             "roofline": {
                 "bound": "hbm",

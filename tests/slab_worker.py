@@ -11,16 +11,22 @@ from yalla_amd import slab as slab_mod
 from yalla_amd.solution import Solution
 
 
-def main(out):
+def main(out, backend="oracle"):
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    lib = _ffi.bind(build_oracle() if rank == 0 else None or build_oracle())
-    n, gs = 3000, 50
+    if backend == "device":  # both ranks on GPU 0, device buffers staged through the host
+        import torch
+        torch.cuda.set_device(0)
+        lib = _ffi.device_lib()
+        n, gs, buffers = 40000, 50, "cuda:0"
+    else:
+        lib = _ffi.bind(build_oracle() if rank == 0 else None or build_oracle())
+        n, gs, buffers = 3000, 50, "cpu"
     with Solution("springs_grid", n, gs, 1.0, lib=lib) as s:
         s.random_sphere(0.5, 3)
         X0 = s.h_X[:n].copy()
     bounds = slab_mod.slab_bounds(X0[:, 2], world)
-    sl = slab_mod.Slab("springs_grid", X0, rank, world, bounds, gs, lib=lib, device="cpu")
+    sl = slab_mod.Slab("springs_grid", X0, rank, world, bounds, gs, lib=lib, device=buffers)
     comm = slab_mod.DistComm()
     for _ in range(6):
         slab_mod.step([sl], comm, 0.003)
@@ -40,4 +46,4 @@ def main(out):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(*sys.argv[1:])

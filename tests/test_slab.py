@@ -88,6 +88,25 @@ def test_two_gloo_ranks_match_undivided_system(oracle, tmp_path):
 
 
 @pytest.mark.gpu
+def test_two_ranks_sharing_one_gpu_match_undivided_system(device, tmp_path):
+    """The one-process-per-rank path on the device: DistComm, torch device buffers handed to
+    the engine, world_size 2.  RCCL refuses two ranks on one GPU, so the transport is gloo
+    with the messages staged through host memory; everything else is what bench.py runs."""
+    out = tmp_path / "slab_gloo_device.npz"
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.path.join(ROOT, "tests"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", "29612",
+           os.path.join(ROOT, "tests", "slab_worker.py"), str(out), "device"]
+    proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-2000:]
+    got = np.load(out)
+    X0, Xref = reference_run(device, 40000, 50, 0.5, 3, 0.003, 6)
+    assert np.array_equal(got["X0"], X0)
+    scale = np.abs(Xref).max()
+    assert np.abs(got["X"] - Xref).max() <= 1e-5 * scale
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("world", [2, 4])
 def test_slabs_match_undivided_system_device(device, world):
     moved = check(device, 40000, world, 6, 0.004, device="hip")

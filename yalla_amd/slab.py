@@ -232,29 +232,46 @@ class LocalComm:
 
 
 class DistComm:
-    """One slab per process: RCCL ("nccl") on GPUs, gloo on CPU (oracle tests)."""
+    """One slab per process: RCCL ("nccl") on GPUs, gloo on CPU (oracle tests).  With
+    gloo and device buffers (two test ranks sharing one GPU: RCCL refuses that) the
+    messages are staged through host memory."""
 
     def __init__(self):
         import torch.distributed as dist
         self.dist = dist
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.stage_through_host = dist.get_backend() == "gloo"
 
     def exchange(self, slabs, kind):
         (s,) = slabs
         dist = self.dist
-        ops = []
+        ops, staged = [], []
         for d, peer in ((0, self.rank - 1), (1, self.rank + 1)):
-            if s.send[kind, d] is not None:
-                ops.append(dist.P2POp(dist.isend, s.send[kind, d].as_tensor(), peer))
-                ops.append(dist.P2POp(dist.irecv, s.recv[kind, d].as_tensor(), peer))
+            if s.send[kind, d] is None:
+                continue
+            out, into = s.send[kind, d].as_tensor(), s.recv[kind, d].as_tensor()
+            if self.stage_through_host and out.is_cuda:
+                host_in = out.cpu().clone()
+                staged.append((into, host_in))
+                out, into = out.cpu(), host_in
+            ops.append(dist.P2POp(dist.isend, out, peer))
+            ops.append(dist.P2POp(dist.irecv, into, peer))
         if ops:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
+        for device_tensor, host_in in staged:
+            device_tensor.copy_(host_in)
 
     def allreduce(self, slabs):
         import torch
         (s,) = slabs
-        self.dist.all_reduce(s.sum.as_tensor().view(torch.float32))
+        t = s.sum.as_tensor().view(torch.float32)
+        if self.stage_through_host and t.is_cuda:
+            host = t.cpu()
+            self.dist.all_reduce(host)
+            t.copy_(host)
+        else:
+            self.dist.all_reduce(t)
 
 
 def step(slabs, comm, dt, migrate=True):
