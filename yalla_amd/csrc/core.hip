@@ -190,14 +190,18 @@ __global__ __launch_bounds__(BLOCK) void k_scan(int* __restrict__ count,
 __global__ __launch_bounds__(BLOCK) void k_scatter(const int* __restrict__ cube_of,
     const int* __restrict__ rank, const int* __restrict__ offs, int n,
     const int* __restrict__ prev_pid, int n_prev, int* __restrict__ arrival_pid,
-    int* __restrict__ cube_id_sorted, int* __restrict__ arrival_src)
+    int* __restrict__ cube_id_sorted, int* __restrict__ arrival_src,
+    const unsigned* __restrict__ entries, int entry_w, int id_word)
 {
     int s = blockIdx.x * BLOCK + threadIdx.x;
     if (s >= max(n, n_prev)) return;
     int c = cube_of[s];
     if (c < 0) return;
     int slot = offs[c] + rank[s];
-    arrival_pid[slot] = visit(s, prev_pid, n_prev, n);
+    // the id of the visited cell: position s of the visit order, or (rebuild from
+    // sorted cells) the id stored in entry s
+    arrival_pid[slot] = entries ? (int)entries[(size_t)s * entry_w + id_word]
+                                : visit(s, prev_pid, n_prev, n);
     cube_id_sorted[slot] = c;
     if (arrival_src) arrival_src[slot] = s;
 }
@@ -242,10 +246,11 @@ __global__ __launch_bounds__(BLOCK) void k_order(const int* __restrict__ arrival
 // second Heun stage: positions moved a little, the previous sorted arrays are the
 // input, so every read is coalesced or local and nothing is gathered from the
 // original-order arrays.  arrival_src[slot] = index of the cell in the previous
-// sorted arrays; ids come from the previous entries (word ID_WORD of EW words).
+// sorted arrays, arrival_pid[slot] = its id (k_scatter copied it from the entry).
 template<int EW>
-__global__ __launch_bounds__(BLOCK) void k_order_from(const int* __restrict__ arrival_src,
-    const int* __restrict__ cube_id_sorted, const int* __restrict__ offs, int n, int id_word,
+__global__ __launch_bounds__(BLOCK) void k_order_from(const int* __restrict__ arrival_pid,
+    const int* __restrict__ arrival_src, const int* __restrict__ cube_id_sorted,
+    const int* __restrict__ offs, int n,
     const unsigned* __restrict__ prev_entries, const float4* __restrict__ prev_v,
     int* __restrict__ point_id, int* __restrict__ next_prev_pid, unsigned* __restrict__ sorted_out,
     float4* __restrict__ sorted_v_out)
@@ -256,10 +261,9 @@ __global__ __launch_bounds__(BLOCK) void k_order_from(const int* __restrict__ ar
     const int a = offs[c], b = offs[c + 1];
     const int src = arrival_src[s];
     const unsigned* mine = prev_entries + (size_t)src * EW;
-    const int p = (int)mine[id_word];
+    const int p = arrival_pid[s];
     int smaller = 0;
-    for (int t = a; t < b; t++)
-        smaller += (int)prev_entries[(size_t)arrival_src[t] * EW + id_word] < p;
+    for (int t = a; t < b; t++) smaller += arrival_pid[t] < p;
     const int dst = a + smaller;
     point_id[dst] = p;
     next_prev_pid[dst] = p;
@@ -574,7 +578,8 @@ int ya_grid_build_sorted(ya_grid* g, const void* d_X, size_t stride_bytes,
         g->d_cube_start, g->d_cube_end);
     if (n > 0) {
         k_scatter<<<nb_visit, BLOCK, 0, st>>>(g->d_cube_of, g->d_rank, g->d_offs, n,
-            g->d_prev_pid, n_prev, g->d_arrival, g->d_cube_id, stash ? g->d_arrival_src : nullptr);
+            g->d_prev_pid, n_prev, g->d_arrival, g->d_cube_id, stash ? g->d_arrival_src : nullptr,
+            nullptr, 0, 0);
         if (gather && (entry_bytes < stride_bytes + 4 || entry_bytes % 4 || !d_sorted_v || !d_old_v))
             return (int)hipErrorInvalidValue;
         const int entry_f = (int)(entry_bytes / 4);
@@ -629,13 +634,14 @@ int ya_grid_rebuild_sorted(ya_grid* g, const void* d_prev_sorted, size_t entry_b
     k_scan<<<g->n_tiles, BLOCK, 0, st>>>(g->d_count, g->d_tile_sums, g->n_cubes, n, g->d_offs,
         g->d_cube_start, g->d_cube_end);
     if (n > 0) {
-        k_scatter<<<nb, BLOCK, 0, st>>>(g->d_cube_of, g->d_rank, g->d_offs, n, g->d_prev_pid, 0,
-            g->d_arrival, g->d_cube_id, nullptr);
         const int id_word = (int)(point_bytes / 4);
+        k_scatter<<<nb, BLOCK, 0, st>>>(g->d_cube_of, g->d_rank, g->d_offs, n, g->d_prev_pid, 0,
+            g->d_arrival, g->d_cube_id, g->d_arrival_src, (const unsigned*)d_prev_sorted, entry_f,
+            id_word);
 #define YA_ORDER_FROM(EW)                                                                    \
     case EW:                                                                                 \
-        k_order_from<EW><<<nb, BLOCK, 0, st>>>(g->d_arrival, g->d_cube_id, g->d_offs, n,     \
-            id_word, (const unsigned*)d_prev_sorted, (const float4*)d_prev_sorted_v,         \
+        k_order_from<EW><<<nb, BLOCK, 0, st>>>(g->d_arrival, g->d_arrival_src, g->d_cube_id, \
+            g->d_offs, n, (const unsigned*)d_prev_sorted, (const float4*)d_prev_sorted_v,    \
             g->d_point_id, g->d_prev_pid, (unsigned*)d_sorted_out, (float4*)d_sorted_v_out); \
         break;
         switch (entry_f) {
