@@ -945,6 +945,7 @@ public:
         YA_CHECK(ya_malloc((void**)&d_n, sizeof(int)));
         YA_CHECK(ya_malloc((void**)&d_mean, 2 * sizeof(Pt)));
         YA_CHECK(ya_malloc((void**)&d_mean_first, 2 * sizeof(Pt)));
+        YA_CHECK(ya_n_reader_create(&n_reader));
         YA_CHECK(ya_malloc((void**)&d_fix, 4 * sizeof(float)));
         YA_CHECK(ya_malloc((void**)&d_fix_first, 4 * sizeof(float)));
         YA_CHECK(ya_malloc((void**)&d_workspace, ya_reduce_workspace_bytes(n_floats)));
@@ -959,6 +960,7 @@ public:
         ya_free(d_n);
         ya_free(d_mean);
         ya_free(d_mean_first);
+        ya_n_reader_destroy(n_reader);
         ya_free(d_fix);
         ya_free(d_fix_first);
         ya_free(d_workspace);
@@ -983,6 +985,7 @@ protected:
     float3* d_old_v;
     int* d_n;
     float *d_mean, *d_fix, *d_mean_first, *d_fix_first, *d_workspace;
+    ya_n_reader* n_reader = nullptr;
     int sorted_stage_cells = -1;  // stage API: cells in the sorted copy stage 2 may start from
     bool fix_com = true;
     bool fix_com_z = false;
@@ -1065,10 +1068,26 @@ protected:
     template<Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction>
     void take_step(float dt, Generic_forces<Pt> gen_forces)
     {
-        const int n = get_d_n();
-        if (n <= 0) return;
+        const bool sorted_path =
+            Computer<Pt>::use_sorted_pipeline() && ya::is_no_gen_forces<Pt>(gen_forces);
+        int n;
+        if (sorted_path) {
+            // The reference reads n first (solvers.cuh:229) and so must we, model kernels
+            // change it between steps; but the round trip is hidden behind the binning
+            // kernels of the first grid build, which read the count on the device.
+            YA_CHECK(ya_n_read_begin(n_reader, d_n, nullptr));
+            Computer<Pt>::begin_build(d_X, d_n, n_max);
+            YA_CHECK(ya_n_read_end(n_reader, &n));
+            assert(n <= n_max);
+        } else {
+            n = get_d_n();
+        }
+        if (n <= 0) {
+            Computer<Pt>::cancel_build();
+            return;
+        }
 
-        if (Computer<Pt>::use_sorted_pipeline() && ya::is_no_gen_forces<Pt>(gen_forces)) {
+        if (sorted_path) {
             // Sorted-space pipeline: the predictor lives in the cube-sorted copy of
             // the cells, so the second grid build gathers nothing and d_X1 is never
             // materialised.  Same arithmetic, same results.
@@ -1108,6 +1127,8 @@ public:
 
 protected:
     void check_status() {}
+    void begin_build(const Pt*, const int*, int) {}
+    void cancel_build() {}
     void predictor_in_sorted_space(int, float, const float*, int) {}
     void ghosts_in_sorted_space(int, int, const Pt*) {}
     template<Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction>
@@ -1170,6 +1191,20 @@ public:
         ya::Entry<Pt>* d_sorted, float4* d_sorted_v)
     {
         YA_CHECK(ya_grid_build_sorted(handle, d_X, sizeof(Pt), d_old_v, n, cube_size, d_sorted,
+            sizeof(ya::Entry<Pt>), d_sorted_v, nullptr));
+    }
+    // build_sorted in two halves: the first one reads the count on the device and can be
+    // queued before the host has it (ya_grid_build_sorted_begin / _finish).
+    template<typename Pt>
+    void build_sorted_begin(const Pt* d_X, const int* d_n, const int n_bound, const float cube_size)
+    {
+        YA_CHECK(ya_grid_build_sorted_begin(handle, d_X, sizeof(Pt), d_n, n_bound, cube_size, nullptr));
+    }
+    template<typename Pt>
+    void build_sorted_finish(const int n, const Pt* d_X, const float3* d_old_v,
+        ya::Entry<Pt>* d_sorted, float4* d_sorted_v)
+    {
+        YA_CHECK(ya_grid_build_sorted_finish(handle, d_X, sizeof(Pt), d_old_v, n, d_sorted,
             sizeof(ya::Entry<Pt>), d_sorted_v, nullptr));
     }
     // Same result as build_sorted on the cells held (in any order) by d_prev, read
@@ -1264,11 +1299,24 @@ protected:
                 (const int*)grid.d_cube_id, grid.offsets(), grid.grid_size, grid.n_cubes,
                 ya::cutoff_squared(cube_size), d_dX, has_gen, n_active, d_dX_in_cell_order);
     }
+    // The part of the first stage's grid build that can be queued before the host knows
+    // n (Heun_solver::take_step); pwints then only finishes the build.
+    void begin_build(const Pt* d_X, const int* d_n, const int n_bound)
+    {
+        grid.build_sorted_begin(d_X, d_n, n_bound, cube_size);
+        build_begun = true;
+    }
+    void cancel_build() { build_begun = false; }
+    bool build_begun = false;
     template<Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction>
     void pwints(const int n, const Pt* __restrict__ d_X, const float3* __restrict__ d_old_v,
         Pt* d_dX, const bool has_gen, const int n_active, const bool keep_sorted)
     {
-        grid.build_sorted(n, d_X, d_old_v, cube_size, d_sorted, d_sorted_v);
+        if (build_begun)
+            grid.build_sorted_finish(n, d_X, d_old_v, d_sorted, d_sorted_v);
+        else
+            grid.build_sorted(n, d_X, d_old_v, cube_size, d_sorted, d_sorted_v);
+        build_begun = false;
         forces<pw_int, pw_friction>(n, d_sorted, d_sorted_v, d_dX, has_gen, n_active,
             keep_sorted ? d_dX_sorted : nullptr);
     }

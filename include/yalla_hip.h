@@ -29,7 +29,7 @@ extern "C" {
 /* The libraries are built with -fvisibility=hidden; only this C ABI is exported. */
 #pragma GCC visibility push(default)
 
-#define YA_ABI_VERSION 3
+#define YA_ABI_VERSION 4
 
 /* Status bits reported by ya_grid_status(). */
 #define YA_STATUS_OUT_OF_GRID 1 /* a cell's cube id fell outside [0, n_cubes):
@@ -53,6 +53,15 @@ int ya_device_synchronize(void);
  * Heun_solver::get_d_n (solvers.cuh:219-225) and Links::get_d_n
  * (links.cuh:58-64); the caller asserts n <= n_max as the reference does. */
 int ya_get_n(const int* d_n, int* n_out);
+
+/* The same read in two halves, so that work which does not need n on the host can be
+ * queued in between: ya_n_read_begin queues the 4-byte copy (into pinned memory) behind
+ * everything already in `stream`, ya_n_read_end waits for it. */
+typedef struct ya_n_reader ya_n_reader;
+int ya_n_reader_create(ya_n_reader** out);
+int ya_n_reader_destroy(ya_n_reader* r);
+int ya_n_read_begin(ya_n_reader* r, const int* d_n, void* stream);
+int ya_n_read_end(ya_n_reader* r, int* n_out);
 
 /* ---- Uniform grid (spatial hash) -------------------------------------- */
 
@@ -90,6 +99,17 @@ int ya_grid_build(ya_grid* g, const void* d_X, size_t stride_bytes, int n,
 int ya_grid_build_sorted(ya_grid* g, const void* d_X, size_t stride_bytes,
     const void* d_old_v, int n, float cube_size, void* d_sorted_X,
     size_t entry_bytes, void* d_sorted_v, void* stream);
+
+/* ya_grid_build_sorted in two halves for a caller that has not read the point count
+ * back yet (Heun_solver::take_step reads n at its start, solvers.cuh:229): _begin bins,
+ * scans and scatters with the count read from *d_n ON THE DEVICE (n_bound >= n only
+ * sizes the launches, n_max will do) and can be queued right after ya_n_read_begin;
+ * _finish (ordering inside the cubes, the sorted copies) needs n on the host. */
+int ya_grid_build_sorted_begin(ya_grid* g, const void* d_X, size_t stride_bytes, const int* d_n,
+    int n_bound, float cube_size, void* stream);
+int ya_grid_build_sorted_finish(ya_grid* g, const void* d_X, size_t stride_bytes,
+    const void* d_old_v, int n, void* d_sorted_X, size_t entry_bytes, void* d_sorted_v,
+    void* stream);
 
 /* The same result as ya_grid_build_sorted, but for cells that already sit in an
  * earlier build's sorted arrays and have moved a little since (the second Heun

@@ -65,8 +65,10 @@ __device__ __forceinline__ int visit(int s, const int* __restrict__ prev_pid, in
 __global__ __launch_bounds__(BLOCK) void k_bin(const float* __restrict__ X,
     int stride_f, int n, float cs, int gs, int n_cubes, const int* __restrict__ prev_pid,
     int n_prev, int* __restrict__ cube_of, int* __restrict__ rank, int* __restrict__ count,
-    int* __restrict__ status, float* __restrict__ stash, int stash_f)
+    int* __restrict__ status, float* __restrict__ stash, int stash_f,
+    const int* __restrict__ d_n)
 {
+    if (d_n) n = min(*d_n, n);  // the count still on its way to the host; n = launch bound
     int s = blockIdx.x * BLOCK + threadIdx.x;
     const int n_visit = max(n, n_prev);
     int id = -1;
@@ -135,8 +137,9 @@ __global__ __launch_bounds__(BLOCK) void k_tile_sum(
 
 __global__ __launch_bounds__(BLOCK) void k_scan(int* __restrict__ count,
     const int* __restrict__ tile_sums, int n_cubes, int n, int* __restrict__ offs,
-    int* __restrict__ cube_start, int* __restrict__ cube_end)
+    int* __restrict__ cube_start, int* __restrict__ cube_end, const int* __restrict__ d_n)
 {
+    if (d_n) n = min(*d_n, n);
     __shared__ int sh[4];
     __shared__ int sh_wave[4];
     // cells in all tiles before this one
@@ -191,8 +194,9 @@ __global__ __launch_bounds__(BLOCK) void k_scatter(const int* __restrict__ cube_
     const int* __restrict__ rank, const int* __restrict__ offs, int n,
     const int* __restrict__ prev_pid, int n_prev, int* __restrict__ arrival_pid,
     int* __restrict__ cube_id_sorted, int* __restrict__ arrival_src,
-    const unsigned* __restrict__ entries, int entry_w, int id_word)
+    const unsigned* __restrict__ entries, int entry_w, int id_word, const int* __restrict__ d_n)
 {
+    if (d_n) n = min(*d_n, n);
     int s = blockIdx.x * BLOCK + threadIdx.x;
     if (s >= max(n, n_prev)) return;
     int c = cube_of[s];
@@ -430,6 +434,7 @@ struct ya_grid {
     int *d_arrival_src;  // visit position of the cell that arrived in a slot
     float* d_stash;      // the points in visit order (ya_grid_build_sorted), lazily sized
     size_t stash_bytes;
+    float* begun_stash;  // the stash the build in progress filled (nullptr: none)
     int *d_prev_pid;  // private copy of the last build's point ids (visit order)
     int n_prev;       // cells in that build; 0 = none / unusable
     int* d_status;
@@ -469,6 +474,44 @@ int ya_device_synchronize(void) { return (int)hipDeviceSynchronize(); }
 int ya_get_n(const int* d_n, int* n_out)
 {
     return (int)hipMemcpy(n_out, d_n, sizeof(int), hipMemcpyDeviceToHost);
+}
+
+struct ya_n_reader {
+    int* h_n;  // pinned
+    hipEvent_t done;
+};
+
+int ya_n_reader_create(ya_n_reader** out)
+{
+    if (!out) return (int)hipErrorInvalidValue;
+    ya_n_reader* r = (ya_n_reader*)calloc(1, sizeof(ya_n_reader));
+    if (!r) return (int)hipErrorOutOfMemory;
+    YA_TRY(hipHostMalloc((void**)&r->h_n, sizeof(int), hipHostMallocDefault));
+    YA_TRY(hipEventCreateWithFlags(&r->done, hipEventDisableTiming));
+    *out = r;
+    return 0;
+}
+int ya_n_reader_destroy(ya_n_reader* r)
+{
+    if (!r) return 0;
+    (void)hipHostFree(r->h_n);
+    (void)hipEventDestroy(r->done);
+    free(r);
+    return 0;
+}
+int ya_n_read_begin(ya_n_reader* r, const int* d_n, void* stream)
+{
+    if (!r || !d_n) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    YA_TRY(hipMemcpyAsync(r->h_n, d_n, sizeof(int), hipMemcpyDeviceToHost, st));
+    return (int)hipEventRecord(r->done, st);
+}
+int ya_n_read_end(ya_n_reader* r, int* n_out)
+{
+    if (!r || !n_out) return (int)hipErrorInvalidValue;
+    YA_TRY(hipEventSynchronize(r->done));
+    *n_out = *r->h_n;
+    return 0;
 }
 
 int ya_grid_create(int n_max, int grid_size, ya_grid** out)
@@ -543,22 +586,20 @@ int ya_grid_offsets(ya_grid* g, const int** d_offs)
     return 0;
 }
 
-int ya_grid_build_sorted(ya_grid* g, const void* d_X, size_t stride_bytes,
-    const void* d_old_v, int n, float cube_size, void* d_sorted_X, size_t entry_bytes,
-    void* d_sorted_v, void* stream)
+// First half of a build: binning, scan and scatter.  With d_n != nullptr the count is
+// read on the device (n_bound only sizes the launches), so these kernels can be queued
+// before the host knows n.
+static int build_begin(ya_grid* g, const void* d_X, size_t stride_bytes, const int* d_n,
+    int n_bound, float cube_size, bool with_stash, hipStream_t st)
 {
-    if (!g || n < 0 || n > g->n_max || stride_bytes < 12 || stride_bytes % 4)
-        return (int)hipErrorInvalidValue;
-    hipStream_t st = (hipStream_t)stream;
     const int stride_f = (int)(stride_bytes / 4);
-    const int nb = ceil_div(n, BLOCK);
-    // the previous order is worth visiting unless the population collapsed
-    const int n_prev = g->n_prev <= 2 * (long)n ? g->n_prev : 0;
-    const int n_visit = n > n_prev ? n : n_prev;
+    // the previous order is worth visiting unless the population collapsed (judged by
+    // the bound when the count itself is not known yet)
+    const int n_prev = g->n_prev <= 2 * (long)n_bound ? g->n_prev : 0;
+    const int n_visit = n_bound > n_prev ? n_bound : n_prev;
     const int nb_visit = ceil_div(n_visit, BLOCK);
-    const bool gather = d_sorted_X != nullptr;
     float* stash = nullptr;
-    if (gather && n > 0) {  // the stash grows with the first use (and with a wider point)
+    if (with_stash && n_bound > 0) {  // the stash grows with the first use (and with a wider point)
         const size_t need = (size_t)g->n_max * stride_bytes;
         if (g->stash_bytes < need) {
             (void)hipFree(g->d_stash);
@@ -569,19 +610,30 @@ int ya_grid_build_sorted(ya_grid* g, const void* d_X, size_t stride_bytes,
         }
         stash = g->d_stash;
     }
-    if (n > 0)
-        k_bin<<<nb_visit, BLOCK, 0, st>>>((const float*)d_X, stride_f, n, cube_size, g->grid_size,
-            g->n_cubes, g->d_prev_pid, n_prev, g->d_cube_of, g->d_rank, g->d_count, g->d_status,
-            stash, stride_f);
+    if (n_bound > 0)
+        k_bin<<<nb_visit, BLOCK, 0, st>>>((const float*)d_X, stride_f, n_bound, cube_size,
+            g->grid_size, g->n_cubes, g->d_prev_pid, n_prev, g->d_cube_of, g->d_rank, g->d_count,
+            g->d_status, stash, stride_f, d_n);
     k_tile_sum<<<g->n_tiles, BLOCK, 0, st>>>(g->d_count, g->d_tile_sums);
-    k_scan<<<g->n_tiles, BLOCK, 0, st>>>(g->d_count, g->d_tile_sums, g->n_cubes, n, g->d_offs,
-        g->d_cube_start, g->d_cube_end);
-    if (n > 0) {
-        k_scatter<<<nb_visit, BLOCK, 0, st>>>(g->d_cube_of, g->d_rank, g->d_offs, n,
+    k_scan<<<g->n_tiles, BLOCK, 0, st>>>(g->d_count, g->d_tile_sums, g->n_cubes, n_bound, g->d_offs,
+        g->d_cube_start, g->d_cube_end, d_n);
+    if (n_bound > 0)
+        k_scatter<<<nb_visit, BLOCK, 0, st>>>(g->d_cube_of, g->d_rank, g->d_offs, n_bound,
             g->d_prev_pid, n_prev, g->d_arrival, g->d_cube_id, stash ? g->d_arrival_src : nullptr,
-            nullptr, 0, 0);
-        if (gather && (entry_bytes < stride_bytes + 4 || entry_bytes % 4 || !d_sorted_v || !d_old_v))
-            return (int)hipErrorInvalidValue;
+            nullptr, 0, 0, d_n);
+    g->begun_stash = stash;
+    return (int)hipGetLastError();
+}
+
+// Second half: ascending ids inside each cube and (optionally) the sorted copies.
+static int build_finish(ya_grid* g, const void* d_X, size_t stride_bytes, const void* d_old_v,
+    int n, void* d_sorted_X, size_t entry_bytes, void* d_sorted_v, hipStream_t st)
+{
+    const int stride_f = (int)(stride_bytes / 4);
+    const int nb = ceil_div(n, BLOCK);
+    const bool gather = d_sorted_X != nullptr;
+    const float* stash = g->begun_stash;
+    if (n > 0) {
         const int entry_f = (int)(entry_bytes / 4);
 #define YA_ORDER(NW)                                                                     \
     case NW:                                                                             \
@@ -614,6 +666,45 @@ int ya_grid_build_sorted(ya_grid* g, const void* d_X, size_t stride_bytes,
     return (int)hipGetLastError();
 }
 
+static bool sorted_args_ok(ya_grid* g, int n, size_t stride_bytes, const void* d_old_v,
+    const void* d_sorted_X, size_t entry_bytes, const void* d_sorted_v)
+{
+    if (!g || n < 0 || n > g->n_max || stride_bytes < 12 || stride_bytes % 4) return false;
+    if (d_sorted_X && (entry_bytes < stride_bytes + 4 || entry_bytes % 4 || !d_sorted_v || !d_old_v))
+        return false;
+    return true;
+}
+
+int ya_grid_build_sorted(ya_grid* g, const void* d_X, size_t stride_bytes,
+    const void* d_old_v, int n, float cube_size, void* d_sorted_X, size_t entry_bytes,
+    void* d_sorted_v, void* stream)
+{
+    if (!sorted_args_ok(g, n, stride_bytes, d_old_v, d_sorted_X, entry_bytes, d_sorted_v))
+        return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    const int rc = build_begin(g, d_X, stride_bytes, nullptr, n, cube_size, d_sorted_X != nullptr, st);
+    if (rc) return rc;
+    return build_finish(g, d_X, stride_bytes, d_old_v, n, d_sorted_X, entry_bytes, d_sorted_v, st);
+}
+
+int ya_grid_build_sorted_begin(ya_grid* g, const void* d_X, size_t stride_bytes, const int* d_n,
+    int n_bound, float cube_size, void* stream)
+{
+    if (!g || !d_n || n_bound < 0 || n_bound > g->n_max || stride_bytes < 12 || stride_bytes % 4)
+        return (int)hipErrorInvalidValue;
+    return build_begin(g, d_X, stride_bytes, d_n, n_bound, cube_size, true, (hipStream_t)stream);
+}
+
+int ya_grid_build_sorted_finish(ya_grid* g, const void* d_X, size_t stride_bytes,
+    const void* d_old_v, int n, void* d_sorted_X, size_t entry_bytes, void* d_sorted_v, void* stream)
+{
+    if (!d_sorted_X ||
+        !sorted_args_ok(g, n, stride_bytes, d_old_v, d_sorted_X, entry_bytes, d_sorted_v))
+        return (int)hipErrorInvalidValue;
+    return build_finish(
+        g, d_X, stride_bytes, d_old_v, n, d_sorted_X, entry_bytes, d_sorted_v, (hipStream_t)stream);
+}
+
 int ya_grid_rebuild_sorted(ya_grid* g, const void* d_prev_sorted, size_t entry_bytes,
     size_t point_bytes, const void* d_prev_sorted_v, int n, float cube_size, void* d_sorted_out,
     void* d_sorted_v_out, void* stream)
@@ -629,15 +720,15 @@ int ya_grid_rebuild_sorted(ya_grid* g, const void* d_prev_sorted, size_t entry_b
     if (n > 0)
         k_bin<<<nb, BLOCK, 0, st>>>((const float*)d_prev_sorted, entry_f, n, cube_size, g->grid_size,
             g->n_cubes, g->d_prev_pid, 0, g->d_cube_of, g->d_rank, g->d_count, g->d_status,
-            nullptr, 0);
+            nullptr, 0, nullptr);
     k_tile_sum<<<g->n_tiles, BLOCK, 0, st>>>(g->d_count, g->d_tile_sums);
     k_scan<<<g->n_tiles, BLOCK, 0, st>>>(g->d_count, g->d_tile_sums, g->n_cubes, n, g->d_offs,
-        g->d_cube_start, g->d_cube_end);
+        g->d_cube_start, g->d_cube_end, nullptr);
     if (n > 0) {
         const int id_word = (int)(point_bytes / 4);
         k_scatter<<<nb, BLOCK, 0, st>>>(g->d_cube_of, g->d_rank, g->d_offs, n, g->d_prev_pid, 0,
             g->d_arrival, g->d_cube_id, g->d_arrival_src, (const unsigned*)d_prev_sorted, entry_f,
-            id_word);
+            id_word, nullptr);
 #define YA_ORDER_FROM(EW)                                                                    \
     case EW:                                                                                 \
         k_order_from<EW><<<nb, BLOCK, 0, st>>>(g->d_arrival, g->d_arrival_src, g->d_cube_id, \
