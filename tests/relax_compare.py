@@ -4,7 +4,7 @@ relaxed_cuboids on the same Solution) for one seed, on the device engine and on 
 oracle: do cells drift away in both?  (Test infrastructure: uses the oracle.)"""
 import ctypes, sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))  # run as: python tests/relax_compare.py [seed]
 import numpy as np
 from yalla_amd import _ffi
 from yalla_amd.solution import Solution

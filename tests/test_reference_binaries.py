@@ -52,7 +52,7 @@ def test_reference_test_inits(tmp_path):
     stale, so that now and then a detached pair of cells keeps drifting (friction_w_neighbour
     hands each the other's velocity).  About one run in eight fails on any faithful
     implementation -- the CPU oracle reproduces a drifting case cell for cell,
-    tools/relax_compare.py (seed 32) -- hence the retries."""
+    tests/relax_compare.py (seed 32) -- hence the retries."""
     run("test_inits", tmp_path, 2, attempts=4)
 
 
