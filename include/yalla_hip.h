@@ -157,6 +157,15 @@ size_t ya_select_workspace_bytes(int n_max);
 int ya_gather_rows(const void* d_src, size_t row_bytes, const int* d_idx, const int* d_count,
     int cap, void* d_dst, void* stream);
 
+/* Appends the rows of up to two fixed-capacity messages behind the n_own rows already in
+ * d_dst: first min(*d_count_lo, cap) rows of d_src_lo, then min(*d_count_hi, cap) rows of
+ * d_src_hi (a NULL count = no message).  The counts are read on the device; the new total
+ * is left in *d_n_out (may be NULL), so that a grid build can be begun on it
+ * (ya_grid_build_sorted_begin) before the host has read the counts. */
+int ya_append_rows(void* d_dst, size_t row_bytes, int n_own, const void* d_src_lo,
+    const int* d_count_lo, const void* d_src_hi, const int* d_count_hi, int cap, int* d_n_out,
+    void* stream);
+
 #pragma GCC visibility pop
 #ifdef __cplusplus
 }

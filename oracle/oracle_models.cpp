@@ -47,6 +47,19 @@ inline void gather_rows(const void* src, size_t row_bytes, const int* idx, const
 }
 inline void copy(void* dst, const void* src, size_t bytes) { memmove(dst, src, bytes); }
 inline int read_int(const void* d) { return *(const int*)d; }
+inline void append_rows(void* dst, size_t row_bytes, int n_own, const void* lo, const void* hi,
+    int cap, size_t payload_offset, int* n_out)
+{
+    int n = n_own;
+    for (const void* m : {lo, hi}) {
+        if (!m) continue;
+        int c = *(const int*)m;
+        c = c < 0 ? 0 : (c > cap ? cap : c);
+        memcpy((char*)dst + (size_t)n * row_bytes, (const char*)m + payload_offset, (size_t)c * row_bytes);
+        n += c;
+    }
+    if (n_out) *n_out = n;
+}
 inline void read_ints(const void* d, int k, int* out) { memcpy(out, d, (size_t)k * sizeof(int)); }
 inline void write_int(void* d, int v) { *(int*)d = v; }
 inline void mean_from_total(const float* total, int n_floats, float* fix)

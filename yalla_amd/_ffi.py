@@ -72,6 +72,7 @@ CORE_ABI = [
     "ya_grid_build_sorted_finish", "ya_grid_rebuild_sorted", "ya_n_reader_create", "ya_n_reader_destroy",
     "ya_n_read_begin", "ya_n_read_end", "ya_grid_status", "ya_reduce_mean",
     "ya_reduce_workspace_bytes", "ya_select_z", "ya_select_workspace_bytes", "ya_gather_rows",
+    "ya_append_rows",
 ]
 
 

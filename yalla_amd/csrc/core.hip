@@ -412,6 +412,24 @@ __global__ __launch_bounds__(BLOCK) void k_gather_rows(const float* __restrict__
     }
 }
 
+// dst rows [n_own, n_own + c_lo) = src_lo rows [0, c_lo), then c_hi rows of src_hi; the
+// counts are the first int of each message (clamped to [0, cap]); a missing message
+// counts as empty.  One thread per float.
+__global__ __launch_bounds__(BLOCK) void k_append_rows(float* __restrict__ dst, int row_f, int n_own,
+    const float* __restrict__ src_lo, const int* __restrict__ count_lo,
+    const float* __restrict__ src_hi, const int* __restrict__ count_hi, int cap,
+    int* __restrict__ n_out)
+{
+    const int c_lo = count_lo ? min(max(*count_lo, 0), cap) : 0;
+    const int c_hi = count_hi ? min(max(*count_hi, 0), cap) : 0;
+    const long total = (long)(c_lo + c_hi) * row_f;
+    for (long e = (long)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (long)gridDim.x * BLOCK) {
+        const long lo_floats = (long)c_lo * row_f;
+        dst[(size_t)n_own * row_f + e] = e < lo_floats ? src_lo[e] : src_hi[e - lo_floats];
+    }
+    if (n_out && blockIdx.x == 0 && threadIdx.x == 0) *n_out = n_own + c_lo + c_hi;
+}
+
 template<int NW>
 int launch_reduce(const float* v, int n, float* out, float* ws, hipStream_t st)
 {
@@ -807,6 +825,23 @@ int ya_gather_rows(const void* d_src, size_t row_bytes, const int* d_idx, const 
     if (blocks > 4096) blocks = 4096;
     k_gather_rows<<<blocks, BLOCK, 0, (hipStream_t)stream>>>(
         (const float*)d_src, row_f, d_idx, d_count, cap, (float*)d_dst);
+    return (int)hipGetLastError();
+}
+
+int ya_append_rows(void* d_dst, size_t row_bytes, int n_own, const void* d_src_lo,
+    const int* d_count_lo, const void* d_src_hi, const int* d_count_hi, int cap, int* d_n_out,
+    void* stream)
+{
+    if (!d_dst || row_bytes < 4 || row_bytes % 4 || n_own < 0 || cap < 0 ||
+        (d_count_lo && !d_src_lo) || (d_count_hi && !d_src_hi))
+        return (int)hipErrorInvalidValue;
+    const int row_f = (int)(row_bytes / 4);
+    long floats = 2L * cap * row_f;
+    int blocks = (int)((floats + BLOCK - 1) / BLOCK);
+    if (blocks < 1) blocks = 1;
+    if (blocks > 4096) blocks = 4096;
+    k_append_rows<<<blocks, BLOCK, 0, (hipStream_t)stream>>>((float*)d_dst, row_f, n_own,
+        (const float*)d_src_lo, d_count_lo, (const float*)d_src_hi, d_count_hi, cap, d_n_out);
     return (int)hipGetLastError();
 }
 

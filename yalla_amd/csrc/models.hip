@@ -55,6 +55,14 @@ inline int read_int(const void* d)
     YA_CHECK(ya_memcpy_d2h(&v, d, sizeof(int)));
     return v;
 }
+inline void append_rows(void* dst, size_t row_bytes, int n_own, const void* lo, const void* hi,
+    int cap, size_t payload_offset, int* n_out)
+{
+    // a message = 16-byte header {int count}, then the rows
+    YA_CHECK(ya_append_rows(dst, row_bytes, n_own, lo ? (const char*)lo + payload_offset : nullptr,
+        (const int*)lo, hi ? (const char*)hi + payload_offset : nullptr, (const int*)hi, cap, n_out,
+        nullptr));
+}
 inline void read_ints(const void* d, int k, int* out)
 {
     YA_CHECK(ya_memcpy_d2h(out, d, (size_t)k * sizeof(int)));
