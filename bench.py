@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--model", default="springs_grid",
                     help="named model of the harness (default: the headline springs_grid)")
     ap.add_argument("--dt", type=float, default=0.001)
-    ap.add_argument("--migrate-every", type=int, default=4,
+    ap.add_argument("--migrate-every", type=int, default=16,
                     help="slab path: hand over cells that left their slab every this many steps")
     ap.add_argument("--slab", action="store_true",
                     help="use the z-slab path (ghost exchange + all-reduce) even on 1 GPU")
