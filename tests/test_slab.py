@@ -111,3 +111,10 @@ def test_two_ranks_sharing_one_gpu_match_undivided_system(device, tmp_path):
 def test_slabs_match_undivided_system_device(device, world):
     moved = check(device, 40000, world, 6, 0.004, device="hip")
     assert moved >= 0
+
+
+@pytest.mark.gpu
+def test_postponed_migration_device(device):
+    """Cells that left their slab are handed over every 4th step only (what bench.py does)."""
+    moved = check(device, 40000, 3, 12, 0.004, device="hip", migrate_every=4)
+    assert moved >= 0
