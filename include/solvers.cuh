@@ -505,20 +505,34 @@ __global__ __launch_bounds__(FORCE_BLOCK) void grid_force(const int n,
     int anchor0 = 0, anchor1 = 0, anchor2 = 0;  // LDS index a queued offset is relative to
     int slot0 = 0, slot1 = 0, slot2 = 0;        // the same anchors as slots of the sorted arrays
 
+    // Row bounds of a plane: six workgroup-uniform and six per-lane reads of offs[].
+    // Those of plane p + 1 are requested while plane p computes, so that a plane's
+    // staging loads do not queue behind a round trip to L2 for its bounds.
+    int next_lo[3], next_hi[3], next_begin[3], next_end[3];
+#define YA_ROW_BOUNDS(plane_)                                                          \
+    _Pragma("unroll") for (int r = 0; r < 3; r++)                                      \
+    {                                                                                  \
+        const int off = stencil_row_offset(3 * (plane_) + r, gs);                      \
+        /* The reference indexes cube_start/end without bounds checks               */ \
+        /* (solvers.cuh:444); out-of-grid cubes are treated as empty here.          */ \
+        next_lo[r] = offs[min(max(c_lo + off - 1, 0), n_cubes)];                       \
+        next_hi[r] = offs[min(max(c_hi + off + 2, 0), n_cubes)];                       \
+        next_begin[r] = offs[min(max(c + off - 1, 0), n_cubes)];                       \
+        next_end[r] = offs[min(max(c + off + 2, 0), n_cubes)];                         \
+    }
+    YA_ROW_BOUNDS(0)
     for (int plane = 0; plane < 3; plane++) {
         // The plane's three rows, concatenated: row r occupies [v0[r], v0[r+1]).
         int wg_begin[3], v0[4], k_begin[3], k_end[3];
         v0[0] = 0;
 #pragma unroll
         for (int r = 0; r < 3; r++) {
-            const int off = stencil_row_offset(3 * plane + r, gs);
-            // The reference indexes cube_start/end without bounds checks
-            // (solvers.cuh:444); out-of-grid cubes are treated as empty here.
-            wg_begin[r] = offs[min(max(c_lo + off - 1, 0), n_cubes)];
-            v0[r + 1] = v0[r] + offs[min(max(c_hi + off + 2, 0), n_cubes)] - wg_begin[r];
-            k_begin[r] = offs[min(max(c + off - 1, 0), n_cubes)];
-            k_end[r] = active ? offs[min(max(c + off + 2, 0), n_cubes)] : k_begin[r];
+            wg_begin[r] = next_lo[r];
+            v0[r + 1] = v0[r] + next_hi[r] - wg_begin[r];
+            k_begin[r] = next_begin[r];
+            k_end[r] = active ? next_end[r] : k_begin[r];
         }
+        if (plane < 2) { YA_ROW_BOUNDS(plane + 1) }
         const int total = v0[3];
 
         for (int chunk = 0; chunk < total; chunk += CAP) {
@@ -644,6 +658,8 @@ __global__ __launch_bounds__(FORCE_BLOCK) void grid_force(const int n,
         if (d_dX_sorted) d_dX_sorted[s] = dX;  // for the sorted-space Euler stage
     }
 }
+
+#undef YA_ROW_BOUNDS
 
 // Gabriel-graph force (replaces compute_cube_gabriel, solvers.cuh:509-602): the
 // candidates inside the cut-off are collected per thread, ordered by distance,
