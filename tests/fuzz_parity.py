@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Randomised bit-exact parity sweep, device engine vs CPU oracle (test infrastructure;
+run on a GPU box: python tests/fuzz_parity.py [cases] [first_seed]).  Draws system size,
+density, cube size, grid size, functor, point type, time step and step count; for every case
+positions, old velocities and the four grid arrays must match bit for bit.  The pytest
+suite runs a short fixed slice of the same generator (test_parity_gpu.py)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+from yalla_amd.solution import Solution
+
+MODELS = ["springs_grid", "clipped_grid", "relu_grid", "relu_po_grid"]  # + - * / sqrt only
+
+
+def draw(seed):
+    rng = np.random.default_rng(seed)
+    model = MODELS[rng.integers(len(MODELS))]
+    n = int(rng.choice([1, 2, 3, 63, 64, 65, 255, 256, 257, 300, 1000, 3000, 7000, 20000]))
+    if rng.random() < 0.5:
+        n = int(rng.integers(1, 9000))
+    dist = float(rng.choice([0.08, 0.15, 0.3, 0.5, 0.75, 1.2, 2.5]))
+    cs = float(rng.choice([0.5, 1.0, 1.0, 1.7]))
+    radius = (n / 0.64) ** (1 / 3) * dist / 2
+    gs = int(2 * (int(radius / cs) + 8) + rng.integers(0, 3))
+    # very dense systems push hard (hundreds of overlapping neighbours): small steps
+    dt = float(rng.choice([0.001, 0.01, 0.05])) if dist >= 0.3 else 1e-4
+    steps = int(rng.integers(1, 4))
+    return dict(model=model, n=n, gs=max(gs, 8), cs=cs, dist=dist, seed=int(seed), dt=dt, steps=steps)
+
+
+def run_case(oracle, device, c):
+    out = []
+    for lib in (oracle, device):
+        with Solution(c["model"], c["n"], c["gs"], c["cs"], lib=lib) as s:
+            if lib is oracle:
+                assert s.set_reduce_order(1) == 0
+            s.random_sphere(c["dist"], c["seed"])
+            s.take_step(c["dt"], c["steps"])
+            out.append((s.positions(), s.old_v()[:c["n"]], s.grid()))
+    (Xo, vo, go), (Xd, vd, gd) = out
+    ok = np.array_equal(Xo.view(np.uint32), Xd.view(np.uint32)) and \
+        np.array_equal(vo.view(np.uint32), vd.view(np.uint32))
+    for name, a, b in zip(("cube_id", "point_id", "cube_start", "cube_end"), go, gd):
+        if name in ("cube_id", "point_id"):
+            a, b = a[:c["n"]], b[:c["n"]]
+        ok = ok and np.array_equal(a, b)
+    return ok
+
+
+if __name__ == "__main__":
+    from yalla_amd import _ffi
+    from conftest import build_oracle
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    oracle, device = _ffi.bind(build_oracle()), _ffi.device_lib()
+    bad = 0
+    for seed in range(first, first + cases):
+        c = draw(seed)
+        if os.environ.get("FUZZ_VERBOSE"):
+            print(c, flush=True)
+        ok = run_case(oracle, device, c)
+        if not ok:
+            bad += 1
+            print("MISMATCH", c, flush=True)
+    print(f"{cases - bad} of {cases} cases bit-exact")
+    sys.exit(1 if bad else 0)

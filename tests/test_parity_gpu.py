@@ -102,6 +102,15 @@ def test_both_second_stage_pipelines_agree(oracle, device):
             assert np.array_equal(a, b), model
 
 
+def test_randomised_configurations_bit_exact(oracle, device):
+    """A fixed slice of tests/fuzz_parity.py's generator: sizes around the wavefront /
+    workgroup boundaries, sparse to very dense systems, cube sizes, functors, point types."""
+    import fuzz_parity
+    for seed in range(1000, 1040):
+        case = fuzz_parity.draw(seed)
+        assert fuzz_parity.run_case(oracle, device, case), case
+
+
 def test_device_kernels_really_ran(device):
     """Guards against a silent fallback: the HIP force kernel launches are
     counted by the engine's own event profiler (2 per take_step)."""
