@@ -22,9 +22,10 @@ def draw(seed):
     dist = float(rng.choice([0.08, 0.15, 0.3, 0.5, 0.75, 1.2, 2.5]))
     cs = float(rng.choice([0.5, 1.0, 1.0, 1.7]))
     radius = (n / 0.64) ** (1 / 3) * dist / 2
-    gs = int(2 * (int(radius / cs) + 8) + rng.integers(0, 3))
+    # room to move: dense spring systems overshoot by tens of units within a few steps
+    gs = int(2 * (int((radius + 30) / cs) + 2) + rng.integers(0, 3))
     # very dense systems push hard (hundreds of overlapping neighbours): small steps
-    dt = float(rng.choice([0.001, 0.01, 0.05])) if dist >= 0.3 else 1e-4
+    dt = 1e-4 if dist < 0.3 else float(rng.choice([0.001, 0.01] if dist < 0.75 else [0.001, 0.01, 0.05]))
     steps = int(rng.integers(1, 4))
     return dict(model=model, n=n, gs=max(gs, 8), cs=cs, dist=dist, seed=int(seed), dt=dt, steps=steps)
 
