@@ -288,6 +288,12 @@ __global__ __launch_bounds__(TILE_BLOCK) void tile_force(const int n,
         }
         __syncthreads();
         if (i < n) {
+            // unrolled: the pairs' distance / functor chains are independent and overlap,
+            // the sums stay in j order
+#ifndef YA_TILE_UNROLL
+#define YA_TILE_UNROLL 4
+#endif
+#pragma unroll YA_TILE_UNROLL
             for (int k = 0; k < n_tile; k++) {
                 const int j = tile_start + k;
                 Pt r = Xi - sh_X[k];
