@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Randomised check of the z-slab decomposition on the device (test infrastructure; run on a GPU
+box: python tests/fuzz_slab.py [cases] [first_seed]): W slabs of one system on one GPU
+(LocalComm) against the undivided system; system size, slab count, step, step count and
+migration interval are drawn.  Criterion: 1e-5 relative for all but a handful of cells.  The
+COM sum is reassociated across slabs (1e-7 relative per step), and the spring force of the
+benchmark model is cut off at cube_size where it is NOT zero: a pair within rounding of the
+cut-off interacts in one run and not in the other, which moves two cells by 0.5 dt at once
+(about two such pairs per step per 40 000 cells) -- those cells are counted, not tolerated
+silently.  Slabs thinner than the ghost layer (tiny systems in many slabs) are skipped: a
+cell's neighbours would sit two slabs away."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import test_slab
+from yalla_amd import _ffi
+
+if __name__ == "__main__":
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+    device = _ffi.device_lib()
+    bad = 0
+    for seed in range(first, first + cases):
+        rng = np.random.default_rng(seed)
+        n = int(rng.integers(500, 60000))
+        world = int(rng.integers(1, 7))
+        steps = int(rng.integers(1, 13))
+        dt = float(rng.choice([0.001, 0.004]))
+        every = int(rng.choice([1, 2, 4]))
+        case = dict(n=n, world=world, steps=steps, dt=dt, migrate_every=every, seed=seed)
+        X0, Xref = test_slab.reference_run(device, n, 50, 0.5, 3, dt, steps)
+        bounds = test_slab.slab_mod.slab_bounds(X0[:, 2], world)
+        if world > 2 and np.diff(bounds[1:-1]).min() < 1.25:
+            print("skip", case, "(a slab thinner than the ghost layer: Slab() refuses)", flush=True)
+            continue
+        X, moved = test_slab.slab_run(device, X0, world, 50, dt, steps, "hip", every)
+        diff = np.abs(X - Xref).max(axis=1)
+        scale = np.abs(Xref).max()
+        off = int((diff > 1e-5 * scale).sum())
+        ok = off <= max(4, n // 2000) and diff.max() <= 2.0 * steps * dt
+        bad += not ok
+        print("ok  " if ok else "FAIL", case, "moved", moved, "cells beyond 1e-5:", off,
+              "max diff %.2e" % diff.max(), flush=True)
+    print(f"{cases - bad} of {cases} slab cases within 1e-5 of the undivided system")
+    sys.exit(1 if bad else 0)

@@ -55,9 +55,9 @@ def check(lib, n, world, steps, dt, device="cpu", migrate_every=1):
     return moved
 
 
-@pytest.mark.parametrize("world", [1, 2, 3, 5])
-def test_slabs_match_undivided_system_oracle(oracle, world):
-    check(oracle, 3000, world, 4, 0.002)
+@pytest.mark.parametrize("world,n", [(1, 3000), (2, 3000), (3, 3000), (5, 9000)])
+def test_slabs_match_undivided_system_oracle(oracle, world, n):
+    check(oracle, n, world, 4, 0.002)
 
 
 def test_cells_migrate_between_slabs_oracle(oracle):
@@ -69,6 +69,13 @@ def test_postponed_migration_oracle(oracle):
     """Migrating every 4th step only: strays stay inside the ghost margin."""
     moved = check(oracle, 3000, 3, 12, 0.002, migrate_every=4)
     assert moved >= 0
+
+
+def test_slabs_thinner_than_the_ghost_layer_are_refused(oracle):
+    X0, _ = reference_run(oracle, 300, 50, 0.5, 3, 0.001, 0)
+    bounds = slab_mod.slab_bounds(X0[:, 2], 6)
+    with pytest.raises(slab_mod.YallaError):
+        slab_mod.Slab("springs_grid", X0, 2, 6, bounds, 50, lib=oracle)
 
 
 def test_two_gloo_ranks_match_undivided_system(oracle, tmp_path):

@@ -124,6 +124,9 @@ class Slab:
         self.rank, self.world = rank, world
         self.z_lo, self.z_hi = float(bounds[rank]), float(bounds[rank + 1])
         halo = cube_size * (1.0 + halo_margin)
+        if world > 2 and float(np.diff(np.asarray(bounds[1:-1], dtype=np.float64)).min()) < halo:
+            raise YallaError("a slab is thinner than the ghost layer (%.3g): a cell's neighbours would "
+                             "sit two slabs away; use fewer slabs for this system" % halo)
         z = X_all[:, 2]
         own = np.nonzero((z >= self.z_lo) & (z < self.z_hi))[0].astype(np.int32)
         # message capacity: the same on every rank (both ends of a message must
