@@ -1047,20 +1047,22 @@ protected:
         Pt* d_in = stage == 1 ? d_X : d_X1;
         Pt* d_rhs = stage == 1 ? d_dX : d_dX1;
         const bool has_gen = !ya::is_no_gen_forces<Pt>(gen_forces);
-        if (stage == 2 && sorted_stage_cells == n && !has_gen) {
-            // sorted-space second stage (see take_step): the own cells were moved by
-            // stage_update(1), the ghost cells' new positions are in d_X1
-            sorted_stage_cells = -1;
-            Computer<Pt>::ghosts_in_sorted_space(n, n_active, d_X1);
-            Computer<Pt>::template pwints_from_sorted<pw_int, pw_friction>(n, d_dX1, n_active);
-            return;
-        }
-        sorted_stage_cells = -1;
         if (has_gen) {
             YA_CHECK(ya_memset_async(d_rhs, 0, (size_t)n * sizeof(Pt), nullptr));
             gen_forces(n, d_in, d_rhs);
         }
-        const bool keep_sorted = stage == 1 && !has_gen && Computer<Pt>::use_sorted_pipeline();
+        if (stage == 2 && sorted_stage_cells == n) {
+            // sorted-space second stage (see take_step): the own cells were moved by
+            // stage_update(1), the ghost cells' new positions are in d_X1 (which the
+            // generic forces above were given, as the reference does)
+            sorted_stage_cells = -1;
+            Computer<Pt>::ghosts_in_sorted_space(n, n_active, d_X1);
+            Computer<Pt>::template pwints_from_sorted<pw_int, pw_friction>(
+                n, d_dX1, n_active, has_gen);
+            return;
+        }
+        sorted_stage_cells = -1;
+        const bool keep_sorted = stage == 1 && Computer<Pt>::use_sorted_pipeline();
         Computer<Pt>::template pwints<pw_int, pw_friction>(
             n, d_in, d_old_v, d_rhs, has_gen, n_active, keep_sorted);
         if (keep_sorted) sorted_stage_cells = n;
@@ -1118,7 +1120,7 @@ protected:
             // this stage's fixed velocity has to outlive the next reduction
             const float* fix = fix_velocity(n, d_dX, fix_com or fix_com_z, fix_com_z, true);
             Computer<Pt>::predictor_in_sorted_space(n, dt, fix, n);
-            Computer<Pt>::template pwints_from_sorted<pw_int, pw_friction>(n, d_dX1, n);
+            Computer<Pt>::template pwints_from_sorted<pw_int, pw_friction>(n, d_dX1, n, false);
             const float* fix1 = fix_velocity(n, d_dX1, fix_com, false);
             heun_step_raw<<<blocks, ya::UPDATE_BLOCK>>>(
                 n, dt, d_dX, fix, d_dX1, fix1, d_X, d_old_v);
@@ -1154,7 +1156,7 @@ protected:
     void predictor_in_sorted_space(int, float, const float*, int) {}
     void ghosts_in_sorted_space(int, int, const Pt*) {}
     template<Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction>
-    void pwints_from_sorted(int, Pt*, int) {}
+    void pwints_from_sorted(int, Pt*, int, bool) {}
     template<Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction>
     void pwints(const int n, const Pt* __restrict__ d_X, const float3* __restrict__ d_old_v,
         Pt* d_dX, const bool has_gen, const int n_active, const bool keep_sorted)
@@ -1357,10 +1359,10 @@ protected:
             n, n_active, d_X1, d_sorted);
     }
     template<Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction>
-    void pwints_from_sorted(const int n, Pt* d_dX, const int n_active)
+    void pwints_from_sorted(const int n, Pt* d_dX, const int n_active, const bool has_gen)
     {
         grid.rebuild_sorted(n, d_sorted, d_sorted_v, cube_size, d_resorted, d_resorted_v);
-        forces<pw_int, pw_friction>(n, d_resorted, d_resorted_v, d_dX, false, n_active, nullptr);
+        forces<pw_int, pw_friction>(n, d_resorted, d_resorted_v, d_dX, has_gen, n_active, nullptr);
     }
 };
 
