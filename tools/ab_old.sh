@@ -1,6 +1,7 @@
 #!/bin/bash
 # usage: ab_old.sh <tag>  -> same-box comparison of this tree against the worktree _old/
 tag=$1
+# _old/ is a scratch worktree of an earlier commit, built in place: git worktree add -f _old <commit>; make -C _old/yalla_amd/csrc
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag; mkdir -p $out
 for rep in 1 2; do
   (cd _old && timeout 300 python bench.py --steps 40 --warmup 5 --no-cpu-baseline > $out/old.json 2> $out/old.err)
