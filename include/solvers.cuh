@@ -429,8 +429,11 @@ struct Stage_cells {
 #ifndef YA_STAGE_CELLS
 #define YA_STAGE_CELLS (3 * YA_FORCE_BLOCK + 160)
 #endif
+#ifndef YA_STAGE_CELLS_MID
+#define YA_STAGE_CELLS_MID YA_STAGE_CELLS  /* 17..32-byte entries: a plane in one chunk beats a sixth workgroup (swept) */
+#endif
     static constexpr int value =
-        sizeof(Entry<Pt>) <= 16 ? YA_STAGE_CELLS : (sizeof(Entry<Pt>) <= 32 ? YA_STAGE_CELLS * 3 / 4 : YA_STAGE_CELLS / 2);
+        sizeof(Entry<Pt>) <= 16 ? YA_STAGE_CELLS : (sizeof(Entry<Pt>) <= 32 ? YA_STAGE_CELLS_MID : YA_STAGE_CELLS / 2);
 };
 #ifndef YA_QUEUE_DEPTH
 #define YA_QUEUE_DEPTH 44
