@@ -504,8 +504,13 @@ int ya_n_reader_create(ya_n_reader** out)
     if (!out) return (int)hipErrorInvalidValue;
     ya_n_reader* r = (ya_n_reader*)calloc(1, sizeof(ya_n_reader));
     if (!r) return (int)hipErrorOutOfMemory;
-    YA_TRY(hipHostMalloc((void**)&r->h_n, sizeof(int), hipHostMallocDefault));
-    YA_TRY(hipEventCreateWithFlags(&r->done, hipEventDisableTiming));
+    hipError_t e = hipHostMalloc((void**)&r->h_n, sizeof(int), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&r->done, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        if (r->h_n) (void)hipHostFree(r->h_n);
+        free(r);
+        return (int)e;
+    }
     *out = r;
     return 0;
 }
@@ -532,16 +537,8 @@ int ya_n_read_end(ya_n_reader* r, int* n_out)
     return 0;
 }
 
-int ya_grid_create(int n_max, int grid_size, ya_grid** out)
+static int grid_allocate(ya_grid* g, int n_max)
 {
-    if (!out || n_max < 0 || grid_size < 1 || grid_size > 1290) return (int)hipErrorInvalidValue;
-    ya_grid* g = (ya_grid*)calloc(1, sizeof(ya_grid));
-    if (!g) return (int)hipErrorOutOfMemory;
-    g->n_max = n_max;
-    g->grid_size = grid_size;
-    g->n_cubes = grid_size * grid_size * grid_size;
-    g->n_tiles = ceil_div(g->n_cubes, SCAN_TILE);
-    g->padded = (size_t)g->n_tiles * SCAN_TILE;
     size_t nb = (size_t)(n_max > 0 ? n_max : 1) * sizeof(int);
     size_t cb = (g->padded + 4) * sizeof(int);
     YA_TRY(hipMalloc(&g->d_cube_id, nb));
@@ -562,6 +559,24 @@ int ya_grid_create(int n_max, int grid_size, ya_grid** out)
     YA_TRY(hipMemset(g->d_cube_start, 0xff, cb));
     YA_TRY(hipMemset(g->d_cube_end, 0xff, cb));
     YA_TRY(hipMemset(g->d_status, 0, sizeof(int)));
+    return 0;
+}
+
+int ya_grid_create(int n_max, int grid_size, ya_grid** out)
+{
+    if (!out || n_max < 0 || grid_size < 1 || grid_size > 1290) return (int)hipErrorInvalidValue;
+    ya_grid* g = (ya_grid*)calloc(1, sizeof(ya_grid));
+    if (!g) return (int)hipErrorOutOfMemory;
+    g->n_max = n_max;
+    g->grid_size = grid_size;
+    g->n_cubes = grid_size * grid_size * grid_size;
+    g->n_tiles = ceil_div(g->n_cubes, SCAN_TILE);
+    g->padded = (size_t)g->n_tiles * SCAN_TILE;
+    const int rc = grid_allocate(g, n_max);
+    if (rc) {  // nothing half-built is handed out or leaked
+        ya_grid_destroy(g);
+        return rc;
+    }
     *out = g;
     return 0;
 }
