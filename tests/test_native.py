@@ -1,0 +1,26 @@
+"""Native test programs written against the header API (tests/native/*.cu, built by
+tests/native/Makefile -- __graft_entry__.build() does it -- and run here on the GPU):
+behaviour the Python harness has no model for."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NATIVE = os.path.join(ROOT, "tests", "native")
+
+
+def run(name, marker):
+    exe = os.path.join(NATIVE, name)
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", NATIVE, name], check=True, capture_output=True)
+    proc = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert proc.returncode == 0 and marker in proc.stdout, proc.stdout[-2000:] + proc.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_wall_forces_known_answers():
+    """wall_forces / link_wall_forces / xy_wall_relu_force (reference links.cuh:142-228):
+    force on cells inside the wall's range, opposite force averaged on the wall node, repeat
+    calls, links added first, float4 points."""
+    run("test_walls", "ALL WALL TESTS PASSED")
