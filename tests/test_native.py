@@ -24,3 +24,10 @@ def test_wall_forces_known_answers():
     force on cells inside the wall's range, opposite force averaged on the wall node, repeat
     calls, links added first, float4 points."""
     run("test_walls", "ALL WALL TESTS PASSED")
+
+
+@pytest.mark.gpu
+def test_initial_condition_shapes():
+    """regular_hexagon / regular_rectangle lattices, seeded random_sphere / disk / cuboid:
+    spacing, bounds, reproducibility, n_0, cell count (reference inits.cuh:14-76,157-247)."""
+    run("test_shapes", "ALL SHAPE TESTS PASSED")
