@@ -31,3 +31,10 @@ def test_initial_condition_shapes():
     """regular_hexagon / regular_rectangle lattices, seeded random_sphere / disk / cuboid:
     spacing, bounds, reproducibility, n_0, cell count (reference inits.cuh:14-76,157-247)."""
     run("test_shapes", "ALL SHAPE TESTS PASSED")
+
+
+@pytest.mark.gpu
+def test_polarity_forces_on_the_device():
+    """The numeric known answers of the reference's tests/test_polarity.cu evaluated in a
+    kernel (device libm), and device against host evaluation of the same code."""
+    run("test_polarity_device", "ALL DEVICE POLARITY TESTS PASSED")
