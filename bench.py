@@ -9,15 +9,29 @@ A "step" is one take_step (two force evaluations + two grid builds + the Heun
 update) over every cell of a random_sphere(0.5, seed 42) system with the
 `spring` functor of examples/springs.cu clipped by the grid cut-off
 (cube_size 1), friction_w_neighbour, dt = 0.001.  One cell-update = one cell
-advanced by one take_step.  N = 1 runs the 1 M-cell configuration the metric is
-quoted on.  Inputs are resident in HBM before the timed region; nothing inside
-it touches the host except take_step's own 4-byte read of n.
+advanced by one take_step.
 
-Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").
+  N = 1   the 1 M-cell configuration the metric is quoted on ("scaling": "weak",
+          the headline line; --cells-total 10000000 gives the 1-GPU 10 M point).
+  N > 1   north_star's multi-GPU configuration: ONE 10 M-cell system cut into N
+          z-slabs, one slab per GPU, ghost layers exchanged point-to-point with
+          RCCL send/recv each Heun stage ("scaling": "strong": total work fixed).
+          Started either by torch.distributed.run (RANK / WORLD_SIZE in the
+          environment) or by this script itself: without WORLD_SIZE it starts the
+          N rank processes (before anything touches a GPU) and relays rank 0's line.
+
+Inputs are resident in HBM before the timed region; nothing inside it touches the
+host except take_step's own 4-byte read of n (and, on the slab path, one 8-byte
+read of the two ghost counts per step).  Prints ONE JSON line on rank 0 (see
+DESIGN.md "Measurement").
 """
 import argparse
+import hashlib
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,17 +40,60 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-# Algorithmic bytes, float3 points: P = 12, V = 12, I = 4.
-FORCE_BYTES_PER_CELL = 12 + 12 + 2 * 4 + 12   # force kernel: r P + V + 2I, w P
-STEP_BYTES_PER_CELL = 13 * 12 + 108           # whole take_step: 13 P + 3 V + 18 I = 264
+FP32_VALU_PEAK_TFLOPS = 157.3
+CUS, SIMDS_PER_CU = 256, 4
+MULTI_GPU_CELLS = 10_000_000   # north_star: "10 M cells ... across 8 x MI355X"
+
+# The named models of the harness that bench.py can time: floats per point, the
+# kernel the roofline object describes, and the workload label.
+MODELS = {
+    "springs_grid": (3, "ya::grid_force<float3, spring, friction_w_neighbour>",
+                     "Solution<float3, Grid_solver>::take_step<spring> (examples/springs.cu functor, "
+                     "friction_w_neighbour)"),
+    "springs_links_grid": (3, "ya::grid_force<float3, spring, friction_w_neighbour>",
+                           "Solution<float3, Grid_solver>::take_step<spring> + link_forces"),
+    "clipped_grid": (3, "ya::grid_force<float3, clipped_spring, friction_w_neighbour>",
+                     "Solution<float3, Grid_solver>::take_step<clipped_spring> (tests/test_solvers.cu)"),
+    "relu_grid": (3, "ya::grid_force<float3, relu_force, friction_w_neighbour>",
+                  "Solution<float3, Grid_solver>::take_step<relu_force> (inits.cuh)"),
+    "sorting_grid": (3, "ya::grid_force<float3, differential_adhesion, friction_w_neighbour>",
+                     "Solution<float3, Grid_solver>::take_step<differential_adhesion> (examples/sorting.cu)"),
+    "relu_po_grid": (5, "ya::grid_force<Po_cell, relu_force, friction_w_neighbour>",
+                     "Solution<Po_cell, Grid_solver>::take_step<relu_force>"),
+    "relu_cell_grid": (7, "ya::grid_force<Cell, relu_force, friction_w_neighbour>",
+                       "Solution<Cell, Grid_solver>::take_step<relu_force> (examples/branching.cu point type)"),
+    "springs_tile": (3, "ya::tile_force<float3, spring, friction_w_neighbour>",
+                     "Solution<float3, Tile_solver>::take_step<spring> (examples/springs.cu)"),
+}
 
 
-def parse():
+def force_bytes_per_cell(n_floats):
+    """Algorithmic bytes of one force launch per cell (SURVEY.md §8(d) force row):
+    r P + V + 2I, w P with P = 4 n_floats, V = 12, I = 4."""
+    return 2 * 4 * n_floats + 12 + 2 * 4
+
+
+def step_bytes_per_cell(n_floats):
+    """Whole take_step: 13 P + 3 V + 18 I; 264 B for float3."""
+    return 13 * 4 * n_floats + 108
+
+
+def gather_model_bytes_per_cell_update(n_floats, dist):
+    """SURVEY.md §8(d)'s second figure: what the reference's kernel structure requests,
+    2 stages x [27 rho (P + V + I) + 27 * 2I] + streaming ~= 2 * 27 rho (P + 16) + 450,
+    rho = cells per unit cube of random_sphere(dist) = 0.64 * 6 / (pi dist^3)."""
+    rho = 0.64 * 6.0 / (math.pi * dist ** 3)
+    return 2 * 27 * rho * (4 * n_floats + 16) + 450
+
+
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--cells", type=int, default=1_000_000, help="cells per GPU")
+    ap.add_argument("--cells-total", type=int, default=0,
+                    help="cells of the whole system (default: 1 M on one GPU, 10 M on several)")
+    ap.add_argument("--cells", type=int, default=0, help="same as --cells-total (kept for scripts)")
     ap.add_argument("--grid-size", type=int, default=0, help="0 = smallest that fits")
     ap.add_argument("--dist", type=float, default=0.5, help="random_sphere spacing")
     ap.add_argument("--cpu-steps", type=int, default=2, help="oracle steps for cpu_baseline")
@@ -58,21 +115,49 @@ def parse():
                     help="attach HIP events to every this-many-th force-kernel launch (odd: both stages)")
     ap.add_argument("--sorted-pipeline", type=int, default=1,
                     help="1 = second Heun stage built from the sorted cells (default), 0 = from d_X1 (A/B)")
-    return ap.parse_args()
+    ap.add_argument("--graph", type=int, default=-1,
+                    help="1 = replay the step as a hipGraph, 0 = plain launches, -1 = the engine's choice")
+    args = ap.parse_args(argv)
+    if args.model not in MODELS:
+        ap.error(f"--model must be one of {sorted(MODELS)}")
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    return args
 
 
-def measured_traffic(kernel_key):
-    """HBM-side bytes per launch of the dominant kernel from the committed
-    rocprofv3 PMC passes of this same command (profiles/r01_traffic.json; FETCH_SIZE
-    and WRITE_SIZE collected in separate --pmc passes, in KiB, FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950)."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+def kernel_source_sha():
+    """Identifies the force kernel's source: the counter file under profiles/ records the
+    value it was measured at, so a stale file is detected on the GPU box (no .git there)."""
+    h = hashlib.sha256()
+    for rel in ("include/solvers.cuh", "include/dtypes.cuh", "yalla_amd/csrc/core.hip",
+                "yalla_amd/csrc/model_functors.h", "yalla_amd/csrc/Makefile"):
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def measured_counters(kernel_key):
+    """Per-launch PMC figures of the dominant kernel from the committed rocprofv3 passes of
+    this same command (profiles/r02_counters.json, written by tools/roofline_json.py):
+    HBM-side traffic (FETCH_SIZE and WRITE_SIZE from separate --pmc passes, KiB, FETCH_SIZE
+    doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950) and the
+    ceilings that bind this kernel.  Returns ({}, None) when there is no record."""
+    path = os.path.join(ROOT, "profiles", "r02_counters.json")
     try:
         with open(path) as f:
             rec = json.load(f)[kernel_key]
-        return (2 * rec["FETCH_SIZE_KiB"] + rec["WRITE_SIZE_KiB"]) * 1024.0
     except (OSError, KeyError, ValueError):
-        return None
+        return {}, None
+    out = {k: rec.get(k) for k in ("valu_issue_frac", "lanes_active_frac", "lds_conflict_frac",
+                                   "lds_busy_frac", "wait_frac", "valu_insts_per_wave")}
+    out["traffic"] = (2 * rec["FETCH_SIZE_KiB"] + rec["WRITE_SIZE_KiB"]) * 1024.0
+    head = {"commit": rec.get("head"), "kernel_sha": rec.get("kernel_sha")}
+    if rec.get("kernel_sha") != kernel_source_sha():
+        # measured on an older kernel: do not pass the numbers off as this build's
+        sys.stderr.write("bench.py: profiles/r02_counters.json was measured on another kernel source "
+                         f"({rec.get('kernel_sha')} != {kernel_source_sha()}); traffic and PMC fractions omitted\n")
+        return {"stale_counters": True}, head
+    return out, head
 
 
 def grid_size_for(n, dist):
@@ -83,7 +168,7 @@ def grid_size_for(n, dist):
     return max(gs, 8)
 
 
-def cpu_baseline(n, gs, dist, steps):
+def cpu_baseline(model, n, gs, dist, dt, steps):
     """The oracle (oracle/, a plain C++ port of the reference's algorithm, one
     thread) timed on the same workload: `steps` take_steps of the same system."""
     from yalla_amd import _ffi
@@ -91,23 +176,63 @@ def cpu_baseline(n, gs, dist, steps):
 
     path = os.path.join(ROOT, "oracle", "_build", "liboracle_models.so")
     lib = _ffi.bind(path)
-    with Solution("springs_grid", n, gs, 1.0, lib=lib) as s:
+    with Solution(model, n, gs, 1.0, lib=lib) as s:
         s.random_sphere(dist, 42)
+        if model.startswith("sorting"):
+            s.set_param("n_cells", n)
         t0 = time.perf_counter()
-        s.take_step(0.001, steps)
-        dt = time.perf_counter() - t0
+        s.take_step(dt, steps)
+        elapsed = time.perf_counter() - t0
     return {
-        "value": n * steps / dt,
+        "value": n * steps / elapsed,
         "unit": "cell-updates/s",
         "cores": 1,
         "host_cores": os.cpu_count(),
         "kind": "port",
-        "sample": f"{steps} take_steps of the same {n}-cell system (oracle/yalla_host.hpp, g++ -O3, 1 thread)",
+        "sample": f"{steps} take_steps of the same {n}-cell {model} system, dt {dt:g} "
+                  "(oracle/yalla_host.hpp, g++ -O3, 1 thread)",
     }
 
 
-def main():
-    args = parse()
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher: start the N rank processes
+    ourselves (children of this process, which never touches a GPU), relay rank 0's
+    JSON line, fail if any rank fails."""
+    port = os.environ.get("MASTER_PORT") or str(free_port())
+    procs = []
+    for rank in range(args.gpus):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus),
+                   LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if rank == 0 else sys.stderr))
+    line, _ = procs[0].communicate()
+    codes = [procs[0].returncode]
+    deadline = time.time() + 120
+    for p in procs[1:]:
+        try:
+            codes.append(p.wait(timeout=max(1.0, deadline - time.time())))
+        except subprocess.TimeoutExpired:
+            p.kill()   # the exact process we started
+            codes.append(-9)
+    sys.stdout.write(line.decode())
+    sys.stdout.flush()
+    if any(codes):
+        sys.exit(f"bench.py: rank exit codes {codes}")
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse(argv)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args, argv)
+
     # RCCL prints a version banner on stdout; the contract is ONE JSON line there.
     real_stdout = os.dup(1)
     os.dup2(2, 1)
@@ -117,17 +242,32 @@ def main():
         local_rank = int(os.environ["YALLA_BENCH_DEVICE"])
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}\n")
         args.gpus = world
+    slab_path = world > 1 or args.slab
+    n_floats, kernel_name, workload = MODELS[args.model]
+    if slab_path:
+        ignored = []
+        if args.model != "springs_grid":
+            sys.exit("bench.py: the z-slab path runs springs_grid only (functors of the other "
+                     "models index per-cell arrays by id); drop --model or run on one GPU")
+        if args.sorted_pipeline != 1:
+            ignored.append("--sorted-pipeline")
+        if args.graph == 1:
+            ignored.append("--graph")
+        if ignored:
+            sys.exit(f"bench.py: {', '.join(ignored)} not available on the z-slab path")
 
     import torch
     import torch.distributed as dist
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the HIP engine has no CPU fallback)")
+    if local_rank >= torch.cuda.device_count():
+        sys.exit(f"bench.py: rank {rank} wants GPU {local_rank}, but only {torch.cuda.device_count()} "
+                 "are visible (one process per GPU)")
     torch.cuda.set_device(local_rank)
-    if world > 1 or args.slab:
+    if slab_path:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
@@ -139,8 +279,7 @@ def main():
 
     from yalla_amd.solution import Solution
 
-    n = args.cells            # cells per GPU (weak scaling: the system grows with N)
-    n_total = n * world
+    n_total = args.cells_total or args.cells or (1_000_000 if world == 1 else MULTI_GPU_CELLS)
     gs = args.grid_size or grid_size_for(n_total, args.dist)
     dt = args.dt
 
@@ -149,14 +288,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if world == 1 and not args.slab:
-        sim = Solution(args.model, n, gs, 1.0)
+    if not slab_path:
+        sim = Solution(args.model, n_total, gs, 1.0)
         sim.random_sphere(args.dist, 42)
         if "grid" in args.model:
             sim.set_param("force_variant", args.force_variant)
             sim.set_param("sorted_pipeline", args.sorted_pipeline)
+            if args.graph >= 0:
+                sim.set_param("graph", args.graph)
         if args.model.startswith("sorting"):
-            sim.set_param("n_cells", n)
+            sim.set_param("n_cells", n_total)
 
         def advance(k):
             sim.take_step(dt, k)
@@ -197,9 +338,9 @@ def main():
     elapsed = time.perf_counter() - t0
     force_ms, launches = sim.profile_read()
     sim.profile(False)
-    if world == 1 and not args.slab:
-        assert sim.get_d_n() == n
-        n_force = n
+    if not slab_path:
+        assert sim.get_d_n() == n_total
+        n_force = n_total
     else:
         slab_mod.step([my_slab], comm, dt, migrate=True)  # untimed: settle ownership, then count
         n_force = my_slab.n_own()   # cells a force launch computes (ghost cells get none)
@@ -214,10 +355,14 @@ def main():
     elapsed = float(t.item())
 
     if rank == 0:
-        total_cells = n * world
-        value = total_cells * args.steps / elapsed
+        value = n_total * args.steps / elapsed
         force_s = force_ms / 1e3 / max(launches, 1)
-        achieved = n_force * FORCE_BYTES_PER_CELL / force_s / 1e9
+        force_bytes = force_bytes_per_cell(n_floats)
+        achieved = n_force * force_bytes / force_s / 1e9 if launches else None
+        headline = (world == 1 and not args.slab and args.model == "springs_grid" and n_total == 1_000_000
+                    and args.dist == 0.5 and args.force_variant == 1)
+        counters, counters_head = measured_counters("grid_force_1M_springs") if headline else ({}, None)
+        gather_bytes = gather_model_bytes_per_cell_update(n_floats, args.dist)
         out = {
             "metric": "cell-updates/sec at 1M cells (Grid_solver)",
             "value": value,
@@ -227,15 +372,15 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "weak" if world == 1 else "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic: random_sphere(%g) seed 42, glibc rand()" % args.dist,
             "config": {
-                "workload": "Solution<float3, Grid_solver>::take_step<spring> (examples/springs.cu "
-                            "functor, friction_w_neighbour), dt 0.001",
-                "cells_per_gpu": n,
-                "total_cells": total_cells,
+                "workload": f"{workload}, dt {dt:g}",
+                "model": args.model,
+                "cells_per_gpu": n_total // world,
+                "total_cells": n_total,
                 "grid_size": gs,
                 "cube_size": 1.0,
                 "parallelism": "1 GPU" if world == 1 else
@@ -245,26 +390,41 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "ya::grid_force<float3, spring, friction_w_neighbour>",
+                "kernel": kernel_name,
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": measured_traffic("grid_force_1M_springs") if world == 1 and n == 1_000_000 else None,
-                "bytes_per_launch": n_force * FORCE_BYTES_PER_CELL,
+                "frac": achieved / HBM_PEAK_GBS if achieved else None,
+                "traffic": counters.get("traffic"),
+                "traffic_head": counters_head,
+                "bytes_per_launch": n_force * force_bytes,
                 "avg_launch_us": force_s * 1e6,
                 "timed_launches": launches,
                 "launches": 2 * args.steps,
-                "whole_step_achieved_GBs": STEP_BYTES_PER_CELL * value / world / 1e9,
+                "whole_step_achieved_GBs": step_bytes_per_cell(n_floats) * value / world / 1e9,
+                # SURVEY.md §8(d)'s second, explicitly labelled figure: bytes the reference's
+                # kernel structure requests (served here from LDS, not from HBM)
+                "gather_model_GBs": gather_bytes * value / world / 1e9,
+                "gather_model_bytes_per_cell_update": gather_bytes,
+                # the ceilings that do bind this kernel (PMC passes under profiles/, same command)
+                "valu_issue_frac": counters.get("valu_issue_frac"),
+                "lanes_active_frac": counters.get("lanes_active_frac"),
+                "lds_conflict_frac": counters.get("lds_conflict_frac"),
+                "lds_busy_frac": counters.get("lds_busy_frac"),
+                "wait_frac": counters.get("wait_frac"),
+                "valu_insts_per_wave": counters.get("valu_insts_per_wave"),
+                "fp32_valu_peak_TFLOPs": FP32_VALU_PEAK_TFLOPS,
             },
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(n, gs, args.dist, args.cpu_steps)
+        if counters.get("stale_counters"):
+            out["roofline"]["stale_counters"] = True
+        if world == 1 and not args.slab and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.model, n_total, gs, args.dist, dt, args.cpu_steps)
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)
-    if world > 1 or args.slab:
+    if slab_path:
         dist.destroy_process_group()
 
 

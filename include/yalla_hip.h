@@ -69,7 +69,11 @@ typedef struct ya_grid ya_grid;
 
 /* Replaces Grid::Grid (solvers.cuh:384-395): allocates the four public
  * arrays d_cube_id[n_max], d_point_id[n_max], d_cube_start[n_cubes],
- * d_cube_end[n_cubes] (n_cubes = grid_size^3) plus private scratch. */
+ * d_cube_end[n_cubes] (n_cubes = grid_size^3) plus private scratch.
+ * grid_size > YA_MAX_GRID_SIZE is refused (hipErrorInvalidValue and a message):
+ * cube ids follow the reference's binary32 expression (solvers.cuh:357-360), which
+ * is exact only while grid_size^3 <= 2^24. */
+#define YA_MAX_GRID_SIZE 256
 int ya_grid_create(int n_max, int grid_size, ya_grid** out);
 int ya_grid_destroy(ya_grid* g);
 

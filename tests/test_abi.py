@@ -90,3 +90,17 @@ def test_product_never_references_the_oracle():
                 if re.search(r"oracle|yalla_host", code, flags=re.I):
                     offenders.append(os.path.join(dirpath, f))
     assert not offenders, offenders
+
+
+def test_grid_sizes_beyond_binary32_exactness_are_refused():
+    """Cube ids are the reference's binary32 expression (solvers.cuh:357-360): exact only
+    up to 256^3 cubes.  ya_grid_create refuses larger grids before it allocates anything
+    (so this runs without a GPU) instead of silently merging neighbouring cubes."""
+    lib = ctypes.CDLL(built(os.path.join(ROOT, "yalla_amd", "libyalla_hip.so")), mode=ctypes.RTLD_LOCAL)
+    lib.ya_grid_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+    handle = ctypes.c_void_p()
+    for gs in (257, 300, 380, 1290):
+        assert lib.ya_grid_create(1000, gs, ctypes.byref(handle)) == 1  # hipErrorInvalidValue
+        assert not handle.value
+    header = open(os.path.join(ROOT, "include", "yalla_hip.h")).read()
+    assert "#define YA_MAX_GRID_SIZE 256" in header

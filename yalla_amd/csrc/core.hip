@@ -564,7 +564,18 @@ static int grid_allocate(ya_grid* g, int n_max)
 
 int ya_grid_create(int n_max, int grid_size, ya_grid** out)
 {
-    if (!out || n_max < 0 || grid_size < 1 || grid_size > 1290) return (int)hipErrorInvalidValue;
+    // cube ids are the reference's binary32 expression (solvers.cuh:357-360, cube_id_of
+    // above): exact only while grid_size^3 <= 2^24.  Beyond 256 neighbouring cubes would
+    // share an id and the stencil miss real neighbours, silently; refuse instead.
+    if (!out || n_max < 0 || grid_size < 1) return (int)hipErrorInvalidValue;
+    if (grid_size > YA_MAX_GRID_SIZE) {
+        fprintf(stderr,
+            "yalla-hip: grid_size %d > %d: cube ids are computed in binary32 like the reference's "
+            "(solvers.cuh:357-360) and are exact only up to %d^3 cubes; use a larger cube_size or "
+            "fewer cubes\n",
+            grid_size, YA_MAX_GRID_SIZE, YA_MAX_GRID_SIZE);
+        return (int)hipErrorInvalidValue;
+    }
     ya_grid* g = (ya_grid*)calloc(1, sizeof(ya_grid));
     if (!g) return (int)hipErrorOutOfMemory;
     g->n_max = n_max;
