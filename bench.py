@@ -47,20 +47,20 @@ MULTI_GPU_CELLS = 10_000_000   # north_star: "10 M cells ... across 8 x MI355X"
 # The named models of the harness that bench.py can time: floats per point, the
 # kernel the roofline object describes, and the workload label.
 MODELS = {
-    "springs_grid": (3, "ya::grid_force<float3, spring, friction_w_neighbour>",
+    "springs_grid": (3, "ya::grid_force_bits<float3, spring, friction_w_neighbour>",
                      "Solution<float3, Grid_solver>::take_step<spring> (examples/springs.cu functor, "
                      "friction_w_neighbour)"),
-    "springs_links_grid": (3, "ya::grid_force<float3, spring, friction_w_neighbour>",
+    "springs_links_grid": (3, "ya::grid_force_bits<float3, spring, friction_w_neighbour>",
                            "Solution<float3, Grid_solver>::take_step<spring> + link_forces"),
-    "clipped_grid": (3, "ya::grid_force<float3, clipped_spring, friction_w_neighbour>",
+    "clipped_grid": (3, "ya::grid_force_bits<float3, clipped_spring, friction_w_neighbour>",
                      "Solution<float3, Grid_solver>::take_step<clipped_spring> (tests/test_solvers.cu)"),
-    "relu_grid": (3, "ya::grid_force<float3, relu_force, friction_w_neighbour>",
+    "relu_grid": (3, "ya::grid_force_bits<float3, relu_force, friction_w_neighbour>",
                   "Solution<float3, Grid_solver>::take_step<relu_force> (inits.cuh)"),
-    "sorting_grid": (3, "ya::grid_force<float3, differential_adhesion, friction_w_neighbour>",
+    "sorting_grid": (3, "ya::grid_force_bits<float3, differential_adhesion, friction_w_neighbour>",
                      "Solution<float3, Grid_solver>::take_step<differential_adhesion> (examples/sorting.cu)"),
-    "relu_po_grid": (5, "ya::grid_force<Po_cell, relu_force, friction_w_neighbour>",
+    "relu_po_grid": (5, "ya::grid_force_bits<Po_cell, relu_force, friction_w_neighbour>",
                      "Solution<Po_cell, Grid_solver>::take_step<relu_force>"),
-    "relu_cell_grid": (7, "ya::grid_force<Cell, relu_force, friction_w_neighbour>",
+    "relu_cell_grid": (7, "ya::grid_force_bits<Cell, relu_force, friction_w_neighbour>",
                        "Solution<Cell, Grid_solver>::take_step<relu_force> (examples/branching.cu point type)"),
     "springs_tile": (3, "ya::tile_force<float3, spring, friction_w_neighbour>",
                      "Solution<float3, Tile_solver>::take_step<spring> (examples/springs.cu)"),
@@ -105,8 +105,8 @@ def parse(argv=None):
                     help="slab path: hand over cells that left their slab every this many steps")
     ap.add_argument("--slab", action="store_true",
                     help="use the z-slab path (ghost exchange + all-reduce) even on 1 GPU")
-    ap.add_argument("--force-variant", type=int, default=1,
-                    help="1 = LDS-staged grid_force (default), 0 = grid_force_direct (A/B)")
+    ap.add_argument("--force-variant", type=int, default=2,
+                    help="2 = grid_force_bits (default), 1 = grid_force (byte FIFO), 0 = grid_force_direct (A/B)")
     ap.add_argument("--backend", default="nccl",
                     help="torch.distributed backend for N > 1 / --slab: nccl (= RCCL), or gloo with "
                          "YALLA_BENCH_DEVICE=0 to rehearse the N-rank path on one GPU (RCCL refuses "
@@ -360,7 +360,7 @@ def main(argv=None):
         force_bytes = force_bytes_per_cell(n_floats)
         achieved = n_force * force_bytes / force_s / 1e9 if launches else None
         headline = (world == 1 and not args.slab and args.model == "springs_grid" and n_total == 1_000_000
-                    and args.dist == 0.5 and args.force_variant == 1)
+                    and args.dist == 0.5 and args.force_variant == 2)
         counters, counters_head = measured_counters("grid_force_1M_springs") if headline else ({}, None)
         gather_bytes = gather_model_bytes_per_cell_update(n_floats, args.dist)
         out = {

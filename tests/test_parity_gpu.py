@@ -69,18 +69,41 @@ def test_other_functors_bit_exact(oracle, device, model):
     assert np.array_equal(vo.view(np.uint32), vd.view(np.uint32))
 
 
-def test_direct_and_staged_force_kernels_agree(oracle, device):
-    """grid_force (LDS-staged, two-phase) and grid_force_direct are the same sums
-    in the same order: bit-identical to each other and to the oracle."""
+def test_all_three_force_kernels_agree(oracle, device):
+    """grid_force_bits (bit-stream hit list, the default), grid_force (byte FIFO) and
+    grid_force_direct (the reference's structure) are the same sums in the same order:
+    bit-identical to each other and to the oracle."""
     n = 30000
     res = []
-    for variant in (0, 1):
+    for variant in (0, 1, 2):
         (Xo, vo, _), (Xd, vd, _) = run_both(
             oracle, device, "springs_grid", n, 50, 1.0, 0.5, 4, 0.001, 2,
             setup=lambda s: s.set_param("force_variant", variant) if s.lib is device else None)
         assert np.array_equal(Xo.view(np.uint32), Xd.view(np.uint32)), variant
         res.append(Xd)
     assert np.array_equal(res[0].view(np.uint32), res[1].view(np.uint32))
+    assert np.array_equal(res[0].view(np.uint32), res[2].view(np.uint32))
+
+
+@pytest.mark.parametrize("model,n,dist,cube", [
+    ("springs_grid", 20000, 0.12, 1.0),    # ~700 cells per cube: rows of hundreds of candidates,
+    ("relu_po_grid", 6000, 0.1, 1.0),      #   the bit stream's stretch-by-stretch path, staging in chunks
+    ("springs_grid", 3000, 0.5, 2.5),      # cut-off 2.5: ~150 candidates per row
+    ("relu_cell_grid", 4000, 0.5, 1.0),    # 32-byte entries
+])
+def test_force_kernels_agree_on_dense_rows(device, model, n, dist, cube):
+    """The three kernels against each other where a lane's row exceeds one pass of the bit
+    stream (and the plane exceeds the staging capacity): bit-identical."""
+    res = []
+    for variant in (0, 1, 2):
+        with Solution(model, n, 50, cube, lib=device) as s:
+            s.random_sphere(dist, 5)
+            s.set_param("force_variant", variant)
+            s.take_step(0.0005, 2)
+            res.append((s.positions(), s.old_v()))
+    for X, v in res[1:]:
+        assert np.array_equal(res[0][0].view(np.uint32), X.view(np.uint32))
+        assert np.array_equal(res[0][1].view(np.uint32), v.view(np.uint32))
 
 
 def test_both_second_stage_pipelines_agree(oracle, device):
