@@ -197,12 +197,15 @@ __global__ void update_wall_node(Pt* d_dX, int wall_idx, int* d_nints)
 }
 
 namespace ya {
-// Interaction counters of the wall node(s), one allocation reused by every call
-// (the reference allocates and leaks a buffer per call, links.cuh:201-209).
+// Interaction counters of the wall node(s), one allocation per host thread reused by
+// every call (the reference allocates and leaks a buffer per call, links.cuh:201-209).
+// Per thread because models step from a worker std::thread while the main thread
+// prepares output (examples/branching.cu:263-280): two solvers stepping in two threads
+// must not share the counters.  Calls of one thread are ordered by the stream.
 inline int* wall_counters(int wall_idx)
 {
-    static int* d_nints = nullptr;
-    static int capacity = 0;
+    static thread_local int* d_nints = nullptr;
+    static thread_local int capacity = 0;
     if (wall_idx + 1 > capacity) {
         if (d_nints) ya_free(d_nints);
         capacity = wall_idx + 1 > 16 ? wall_idx + 1 : 16;

@@ -45,7 +45,16 @@ public:
     {
         char piece[128];
         const int len = snprintf(piece, sizeof(piece), format, args...);
-        buffer.append(piece, len);
+        if (len < 0) return;
+        if ((size_t)len < sizeof(piece)) {
+            buffer.append(piece, len);
+            return;
+        }
+        // longer than the stack buffer (e.g. a long field name): format into the string itself
+        const size_t old_size = buffer.size();
+        buffer.resize(old_size + (size_t)len + 1);
+        snprintf(&buffer[old_size], (size_t)len + 1, format, args...);
+        buffer.resize(old_size + (size_t)len);
     }
     void add(const std::string& s) { buffer += s; }
     // "%g" is what `ostream << float` prints at the default precision of 6

@@ -90,7 +90,8 @@ int ya_sim_set_links(ya_sim* sim, const int* ab, int n_links, float strength);
  * buffers are device memory (host memory on the oracle) of ya_slab_*_bytes(cap)
  * bytes: a 16-byte header {int count} and `cap` rows per field.  One stage is
  *   pack_halo(dir 0 -> lower neighbour, 1 -> upper) ; exchange ; unpack_halo ;
- *   stage_rhs ; stage_sum -> {sum[n_floats], n_own} ; all-reduce ; stage_update
+ *   stage_rhs ; stage_sum -> {sum[n_floats], n_own & 4095, n_own >> 12} (n_floats + 2 floats:
+ *   the count in two pieces that stay exact under a float all-reduce) ; all-reduce ; stage_update
  * and after stage 2: migrate_pack ; exchange ; migrate_unpack.  The exchange
  * itself (RCCL send/recv, all-reduce) is the caller's: yalla_amd/slab.py. */
 int ya_slab_init(ya_sim* sim, float z_lo, float z_hi, float halo_width, const int* global_ids);

@@ -62,15 +62,19 @@ inline void append_rows(void* dst, size_t row_bytes, int n_own, const void* lo, 
 }
 inline void read_ints(const void* d, int k, int* out) { memcpy(out, d, (size_t)k * sizeof(int)); }
 inline void write_int(void* d, int v) { *(int*)d = v; }
+// The cell count travels through the float all-reduce as two exact pieces (low 12 bits and
+// the rest): exact for any total below 2^36 however many ranks add up.
 inline void mean_from_total(const float* total, int n_floats, float* fix)
 {
-    const float inv = (float)(1. / (double)total[n_floats]);
+    const double n = (double)total[n_floats] + 4096. * (double)total[n_floats + 1];
+    const float inv = (float)(1. / n);
     for (int k = 0; k < 3; k++) fix[k] = total[k] * inv;
 }
 inline void pack_sum(const float* sum, int n_floats, int n_own, float* out)
 {
     for (int k = 0; k < n_floats; k++) out[k] = sum[k];
-    out[n_floats] = (float)n_own;
+    out[n_floats] = (float)(n_own & 4095);
+    out[n_floats + 1] = (float)(n_own >> 12);
 }
 }  // namespace harness_ops
 

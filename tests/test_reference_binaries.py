@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF_BIN = os.path.join(ROOT, "oracle", "_ref")
 
 
-def run(name, tmp_path, n_tests, attempts=1):
+def run(name, tmp_path, n_tests, seed=None, expect="ALL TESTS PASSED"):
     exe = os.path.join(REF_BIN, name)
     if not os.path.exists(exe):
         if os.path.isdir("/root/reference/tests"):
@@ -20,13 +20,15 @@ def run(name, tmp_path, n_tests, attempts=1):
                            capture_output=True)
         else:
             pytest.skip(f"{exe} was not built (no reference checkout here)")
-    for attempt in range(attempts):
-        proc = subprocess.run([exe], cwd=tmp_path, capture_output=True, text=True, timeout=600)
-        if "ALL TESTS PASSED" in proc.stdout:
-            break
-    assert "ALL TESTS PASSED" in proc.stdout, proc.stdout[-2000:] + proc.stderr[-2000:]
-    assert f"Tests run: {n_tests}" in proc.stdout
-    assert proc.returncode == 0
+    env = dict(os.environ)
+    if seed is not None:
+        env["YALLA_SEED"] = str(seed)  # include/inits.cuh: pins every "any seed" initial condition
+    proc = subprocess.run([exe], cwd=tmp_path, capture_output=True, text=True, timeout=600, env=env)
+    assert expect in proc.stdout, proc.stdout[-2000:] + proc.stderr[-2000:]
+    if expect == "ALL TESTS PASSED":
+        assert f"Tests run: {n_tests}" in proc.stdout
+        assert proc.returncode == 0
+    return proc.stdout
 
 
 def test_reference_test_dtypes(tmp_path):
@@ -46,14 +48,36 @@ def test_reference_test_links(tmp_path):
 
 
 @pytest.mark.gpu
-def test_reference_test_inits(tmp_path):
-    """Statistical by construction: it seeds from std::random_device, measures ONE random
-    cell's mean neighbour distance, and re-initialises a Solution whose old velocities are
-    stale, so that now and then a detached pair of cells keeps drifting (friction_w_neighbour
-    hands each the other's velocity).  About one run in eight fails on any faithful
-    implementation -- the CPU oracle reproduces a drifting case cell for cell,
-    tests/relax_compare.py (seed 32) -- hence the retries."""
-    run("test_inits", tmp_path, 2, attempts=4)
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_reference_test_inits(tmp_path, seed):
+    """test_inits.cu is statistical: it seeds from std::random_device and asserts on ONE
+    random cell's mean distance to its neighbours (tests/test_inits.cu:33-47).  With the
+    initial conditions pinned (YALLA_SEED, include/inits.cuh) it is deterministic: these
+    seeds pass, every run."""
+    run("test_inits", tmp_path, 2, seed=seed)
+
+
+@pytest.mark.gpu
+def test_reference_test_inits_unlucky_seed_is_the_tests_statistics(tmp_path, oracle, device):
+    """Seed 5 draws a cell whose neighbourhood misses the test's +-0.05 window: the same
+    assertion fails on every run, and the CPU restatement of the reference's algorithm
+    relaxes that sphere (random_sphere(0.6), srand(5), 2000 relu_force steps: what
+    relaxed_sphere does, inits.cuh:95-125) to bit-identical positions -- the failure is a
+    property of the test's draw, not of this engine."""
+    import numpy as np
+    from yalla_amd.solution import Solution
+
+    for _ in range(2):
+        run("test_inits", tmp_path, 2, seed=5, expect="Sphere mean dist to neighbours wrong")
+    out = []
+    for lib in (oracle, device):
+        with Solution("relu_grid", 5000, 50, 1.0, lib=lib) as s:
+            if lib is oracle:
+                s.set_reduce_order(1)
+            s.random_sphere(0.6, 5)
+            s.take_step(0.1, 2000)
+            out.append(s.positions())
+    assert np.array_equal(out[0].view(np.uint32), out[1].view(np.uint32))
 
 
 @pytest.mark.gpu

@@ -68,10 +68,13 @@ inline void read_ints(const void* d, int k, int* out)
     YA_CHECK(ya_memcpy_d2h(out, d, (size_t)k * sizeof(int)));
 }
 inline void write_int(void* d, int v) { YA_CHECK(ya_memcpy_h2d(d, &v, sizeof(int))); }
+// The cell count travels through the float all-reduce as two exact pieces (low 12 bits and
+// the rest): exact for any total below 2^36 however many ranks add up.
 __global__ void k_mean_from_total(const float* total, int n_floats, float* fix)
 {
     // fix = sum * float(1. / n): the reference's Pt / n arithmetic (dtypes.cuh:202-217)
-    const float inv = (float)(1. / (double)total[n_floats]);
+    const double n = (double)total[n_floats] + 4096. * (double)total[n_floats + 1];
+    const float inv = (float)(1. / n);
     if (threadIdx.x < 3) fix[threadIdx.x] = total[threadIdx.x] * inv;
 }
 inline void mean_from_total(const float* total, int n_floats, float* fix)
@@ -81,7 +84,10 @@ inline void mean_from_total(const float* total, int n_floats, float* fix)
 __global__ void k_pack_sum(const float* sum, int n_floats, int n_own, float* out)
 {
     if ((int)threadIdx.x < n_floats) out[threadIdx.x] = sum[threadIdx.x];
-    if ((int)threadIdx.x == n_floats) out[n_floats] = (float)n_own;
+    if ((int)threadIdx.x == n_floats) {
+        out[n_floats] = (float)(n_own & 4095);
+        out[n_floats + 1] = (float)(n_own >> 12);
+    }
 }
 inline void pack_sum(const float* sum, int n_floats, int n_own, float* out)
 {

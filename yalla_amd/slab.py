@@ -10,7 +10,7 @@ is a contiguous key range), one slab per rank / GPU.  Per Heun stage a rank
      via torch.distributed), never a ring collective;
   2. appends the received ghost cells, builds the grid over own + ghosts and
      evaluates forces for its own cells only;
-  3. all-reduces {sum of dX, cell count} (a few floats) for the centre-of-mass
+  3. all-reduces {sum of dX, cell count as two exact floats} (a few floats) for the centre-of-mass
      fix, and updates its own cells;
 
 and after the second stage hands over the cells that left the slab.  The device
@@ -155,7 +155,7 @@ class Slab:
         self.recv = {("halo", d): _Buffer(hb, device) if has[d] else None for d in (0, 1)}
         self.send.update({("mig", d): _Buffer(mb, device) if has[d] else None for d in (0, 1)})
         self.recv.update({("mig", d): _Buffer(mb, device) if has[d] else None for d in (0, 1)})
-        self.sum = _Buffer(4 * (self.n_floats + 1), device)
+        self.sum = _Buffer(4 * (self.n_floats + 2), device)  # sum of dX, cell count in two exact pieces
         self.n_local = len(own)
 
     @staticmethod
