@@ -95,9 +95,7 @@ __host__ __device__ __forceinline__ float reciprocal(const float b)
     const float q1 = __builtin_fmaf(e1, r1, r1);
     const float e2 = __builtin_fmaf(-b, q1, 1.0f);
     float out = __builtin_fmaf(e2, r1, q1);
-#ifndef YA_X_NO_RARE
     if (__builtin_expect(!(a >= 0x1p-64f && a <= 0x1p+64f), 0)) out = 1.0f / b;
-#endif
     return out;
 #else
     return 1. / b;

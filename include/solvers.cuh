@@ -131,9 +131,7 @@ __device__ __forceinline__ float exact_sqrt(float x)
     const float r_up = fmaf(-s_up, s, x);
     float out = r_down <= 0.f ? s_down : s;
     out = r_up > 0.f ? s_up : out;
-#ifndef YA_X_NO_RARE
     if (__builtin_expect(x < 0x1p-96f && x > 0.f, 0)) out = sqrtf(x);
-#endif
     return out;
 }
 
@@ -169,28 +167,6 @@ __device__ __forceinline__ int xcd_contiguous_tile(const int block, const int n_
     const int xcd = block % XCDS, turn = block / XCDS;
     const int q = n_blocks / XCDS, r = n_blocks % XCDS;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + turn;
-}
-
-// The same with two ranges per XCD: the sorted order is z-major, so in a blob of cells the
-// first and last eighths are caps with more surface (fewer neighbours, less work) than the
-// middle ones.  XCD k takes sixteenth k and sixteenth 15 - k: equal work per XCD, and each
-// range is still several cube planes thick (L2 reuse of the stencil planes).
-__device__ __forceinline__ int xcd_paired_tile(const int block, const int n_blocks)
-{
-    constexpr int XCDS = 8;
-    if (n_blocks < 64) return xcd_contiguous_tile(block, n_blocks);
-    const int xcd = block % XCDS, turn = block / XCDS;
-    const int Q = n_blocks / XCDS, R = n_blocks % XCDS;  // XCD x runs Q + (x < R) blocks
-    // first halves (rounded up) of the XCDs' shares in XCD order, then the second halves in
-    // reverse XCD order: sixteen consecutive ranges of the sorted cells
-    const int a_hi = (Q + 2) / 2, a_lo = (Q + 1) / 2, b_hi = (Q + 1) / 2, b_lo = Q / 2;
-    const int first = xcd < R ? a_hi : a_lo;
-    const int before = min(xcd, R) * a_hi + max(xcd - R, 0) * a_lo;
-    if (turn < first) return before + turn;
-    const int all_first = R * a_hi + (XCDS - R) * a_lo;
-    const int second_upto = min(xcd + 1, R) * b_hi + max(xcd + 1 - R, 0) * b_lo;  // XCDs 0 .. xcd
-    const int all_second = R * b_hi + (XCDS - R) * b_lo;
-    return all_first + (all_second - second_upto) + (turn - first);
 }
 
 // Test hook: the same for ya::reciprocal (dtypes.cuh) against 1.0f / x.
@@ -696,8 +672,9 @@ __global__ __launch_bounds__(FORCE_BLOCK) void grid_force(const int n,
 
 
 // ---------------------------------------------------------------------------------
-// grid_force_bits: the same two-phase kernel with the hit list kept as a BIT STREAM
-// (one bit per tested candidate, in the reference's order) instead of a byte FIFO.
+// grid_force_bits (the default): the same two-phase kernel with the hit list kept as a BIT
+// STREAM (one bit per tested candidate, in the reference's order) instead of a byte FIFO,
+// in one-wavefront workgroups.
 //
 //   phase 1  per candidate: one 16-byte LDS read, the squared distance and
 //            `m = 2 m + (d2 < cut2)` -- a compare and an add-with-carry.  A word is
@@ -705,28 +682,31 @@ __global__ __launch_bounds__(FORCE_BLOCK) void grid_force(const int n,
 //            FIFO issued four ds_write_b8) in [word][thread] order: no bank conflicts.
 //            Rows are padded to a multiple of four bits, so there is no one-candidate
 //            tail loop: the last group of a row is tested under a mask.
-//   phase 2  pops the set bits highest first (= ascending candidate order): clz, clear,
-//            and the bit position gives the staged cell through three per-lane row
-//            offsets.  The next word of the stream is requested one hit ahead.
+//   phase 2  pops the set bits highest first (= ascending candidate order), two per trip:
+//            the second hit's LDS / global loads are in flight while the first one's
+//            arithmetic runs (the sums stay in order).  The bit position gives the
+//            staged cell through three per-lane row offsets; the next word of the stream
+//            is requested one trip ahead.
 //
 // A pass covers 32 * YA_MASK_WORDS candidate bits per lane.  A plane's three rows fit
 // into one pass at any density a model normally runs at (~90 candidates per plane at
 // rho = 9.8); a wavefront in which some lane has more falls back to one pass per row
-// stretch.  With 4 words the workgroup needs 20 KiB of LDS (the FIFO kernel: 26 KiB).
+// stretch.  A workgroup is ONE wavefront (64 cells): nothing waits at a workgroup barrier
+// for a slower wavefront, launches of 10^4..10^5 cells spread over four times as many
+// CUs, and the workgroup needs 7 KiB of LDS.  MI355X, same box (tools/micro/force_ab.hip):
+// 242 us per 1 M-cell launch against 260 us for grid_force, 62 against 75 us at 10^5 cells,
+// 803 against 853 us at 4 M.  What bounds it is the VALU issue rate.
 // Results are bit-identical to grid_force / grid_force_direct: same candidates, same
 // order, same arithmetic.
 namespace bits {
 #ifndef YA_BITS_BLOCK
-#define YA_BITS_BLOCK 256
+#define YA_BITS_BLOCK 64
 #endif
 #ifndef YA_MASK_WORDS
 #define YA_MASK_WORDS 4
 #endif
-#ifndef YA_BITS_WAVES
-#define YA_BITS_WAVES 6  /* wavefronts per SIMD the register allocation is held to (3- and 4-float points) */
-#endif
-#ifndef YA_BITS_STAGE_V
-#define YA_BITS_STAGE_V 0  /* 1: old_v of the staged cells in LDS as well (A/B) */
+#ifndef YA_BITS_POPS
+#define YA_BITS_POPS 2  /* hits popped per trip of phase 2 (1 or 2) */
 #endif
 constexpr int BLOCK = YA_BITS_BLOCK;
 constexpr int WORDS = YA_MASK_WORDS;
@@ -739,14 +719,6 @@ struct Stage {
 #define YA_BITS_STAGE_CELLS (3 * YA_BITS_BLOCK + 160)
 #endif
     static constexpr int value = sizeof(Entry<Pt>) <= 32 ? YA_BITS_STAGE_CELLS : YA_BITS_STAGE_CELLS / 2;
-};
-
-// Occupancy the register allocator is asked for: light functors on float3 / float4 points
-// are held to YA_BITS_WAVES wavefronts per SIMD; larger points carry polarity / kinetics
-// functors that need their registers (no bound: spilling them costs more than occupancy).
-template<typename Pt>
-struct Waves {
-    static constexpr int value = YA_BITS_WAVES > 0 && sizeof(Pt) <= 16 ? YA_BITS_WAVES : 1;
 };
 
 // m = 2 m + (d2 < cut2)
@@ -762,16 +734,11 @@ __device__ __forceinline__ void shift_in(unsigned& m, const float d2, const floa
 // empty if b_r >= e_r), at most PASS_BITS bits after padding each to a multiple of four.
 // shift_r turns an LDS index of segment r into a slot of the sorted arrays.
 template<typename Pt, Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction>
-__device__ __forceinline__ void pass(const Entry<Pt>* __restrict__ sh_e, const float4* __restrict__ sh_v,
-    Lds_word* const words, const int b0, const int e0, const int b1, const int e1, const int b2,
-    const int e2, const int shift0, const int shift1, const int shift2,
-    const float4* __restrict__ sorted_v, const Pt& Xi, const int i, const float cut2, Pt& F,
-    float3& sum_v, float& sum_friction)
+__device__ __forceinline__ void pass(const Entry<Pt>* __restrict__ sh_e, Lds_word* const words,
+    const int b0, const int e0, const int b1, const int e1, const int b2, const int e2,
+    const int shift0, const int shift1, const int shift2, const float4* __restrict__ sorted_v,
+    const Pt& Xi, const int i, const float cut2, Pt& F, float3& sum_v, float& sum_friction)
 {
-#ifndef YA_ABL
-#define YA_ABL 0  /* timing ablations, tools/micro only: 1 no phase 2, 2 phase 2 without the pair arithmetic, 3 no old_v gather, 4 no pass at all, 5 no phase 1 tests */
-#endif
-    if (YA_ABL == 4) return;
     // ---- phase 1 ----
     unsigned m = 0;
     int p = 0;  // bits emitted
@@ -811,29 +778,17 @@ __device__ __forceinline__ void pass(const Entry<Pt>* __restrict__ sh_e, const f
     if (p & 31) *mp = m << (32 - (p & 31));  // left-align the last, partial word
 
     // ---- phase 2 ----
-    if (YA_ABL == 1) {
-        sum_friction += __int_as_float(m + p);
-        return;
-    }
     int left = ((p + 31) >> 5) - 1;  // words after the current one
     unsigned cur = p > 0 ? words[0] : 0u;
     Lds_word* rp = words + BLOCK;
     unsigned nxt = *rp;  // one spare row keeps this in bounds
     int wbase = 0;
-#ifndef YA_BITS_POPS
-#define YA_BITS_POPS 1  /* hits popped per trip: 2 = the second one's loads overlap the first one's arithmetic */
-#endif
 #define YA_BITS_LOAD(q_, other_, v_)                                                   \
     {                                                                                  \
         const bool in2 = (q_) >= p2, in1 = (q_) >= p1;                                 \
         const int t = (q_) + (in2 ? d2_ : (in1 ? d1 : d0));                            \
         other_ = sh_e[t];                                                              \
-        if (YA_ABL == 3)                                                               \
-            v_ = float4{1.f, 2.f, 3.f, 4.f};                                           \
-        else if (YA_BITS_STAGE_V)                                                      \
-            v_ = sh_v[t];                                                              \
-        else                                                                           \
-            v_ = sorted_v[(unsigned)(t + (in2 ? shift2 : (in1 ? shift1 : shift0)))];   \
+        v_ = sorted_v[(unsigned)(t + (in2 ? shift2 : (in1 ? shift1 : shift0)))];       \
     }
 #define YA_BITS_PAIR(other_, v_)                                                       \
     {                                                                                  \
@@ -862,37 +817,17 @@ __device__ __forceinline__ void pass(const Entry<Pt>* __restrict__ sh_e, const f
             Entry<Pt> other;
             float4 v;
             YA_BITS_LOAD(wbase + pos, other, v)
-            if (YA_ABL == 2) {
-                F.x += other.X.x;
-                sum_friction += __int_as_float(other.id);
-                continue;
-            }
             if (YA_BITS_POPS == 2) {
+                // a second hit of the same word, if there is one: its loads are issued before
+                // the first hit's arithmetic (without one, the first hit's are repeated)
                 const bool second = cur != 0;
                 const int pos_b = second ? __builtin_clz(cur) : pos;
                 cur = second ? cur & (0x7fffffffu >> pos_b) : cur;
                 Entry<Pt> other_b;
                 float4 v_b;
-                YA_BITS_LOAD(wbase + pos_b, other_b, v_b)  // (a repeat of the first hit if there is no second)
-#ifdef YA_X_UNCOND_B  /* timing experiment only: wrong results */
-                Pt F_b = ya::zero<Pt>();
-                float fr_b;
-                {
-                    Pt r = Xi - other_b.X;
-                    float dist = dist3(r.x, r.y, r.z);
-                    F_b = pw_int(Xi, r, dist, i, other_b.id);
-                    fr_b = pw_friction(Xi, r, dist, i, other_b.id);
-                }
-                YA_BITS_PAIR(other, v)
-                F += F_b;
-                sum_friction += fr_b;
-                sum_v.x += fr_b * v_b.x;
-                sum_v.y += fr_b * v_b.y;
-                sum_v.z += fr_b * v_b.z;
-#else
+                YA_BITS_LOAD(wbase + pos_b, other_b, v_b)
                 YA_BITS_PAIR(other, v)
                 if (second) YA_BITS_PAIR(other_b, v_b)
-#endif
             } else {
                 YA_BITS_PAIR(other, v)
             }
@@ -904,7 +839,7 @@ __device__ __forceinline__ void pass(const Entry<Pt>* __restrict__ sh_e, const f
 }  // namespace bits
 
 template<typename Pt, Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction>
-__global__ __launch_bounds__(bits::BLOCK, bits::Waves<Pt>::value) void grid_force_bits(const int n,
+__global__ __launch_bounds__(bits::BLOCK) void grid_force_bits(const int n,
     const Entry<Pt>* __restrict__ sorted, const float4* __restrict__ sorted_v,
     const int* __restrict__ cube_id, const int* __restrict__ offs, const int gs,
     const int n_cubes, const float cut2, Pt* __restrict__ d_dX, const bool has_gen,
@@ -914,25 +849,9 @@ __global__ __launch_bounds__(bits::BLOCK, bits::Waves<Pt>::value) void grid_forc
     constexpr int CAP = bits::Stage<Pt>::value;
     __shared__ __attribute__((aligned(16))) Entry<Pt> sh_e[CAP + 8];  // slack: whole groups are read
     __shared__ unsigned sh_m[(bits::WORDS + 1) * FB];                // [word][thread], one spare row
-#ifdef YA_X_LDS_PAD
-    __shared__ unsigned sh_pad[YA_X_LDS_PAD / 4];
-    if (n < 0) sh_pad[threadIdx.x] = 1, d_dX[0].x = sh_pad[threadIdx.x ^ 1];
-#endif
-#if YA_BITS_STAGE_V
-    __shared__ float4 sh_v[CAP];
-    const float4* const staged_v = sh_v;
-#else
-    const float4* const staged_v = nullptr;
-#endif
     bits::Lds_word* const words = (bits::Lds_word*)sh_m + threadIdx.x;
 
-#ifndef YA_BITS_TILE_MAP
-#define YA_BITS_TILE_MAP 1  /* 0 identity, 1 one range per XCD, 2 two ranges per XCD */
-#endif
-    const int tile = YA_BITS_TILE_MAP == 2 ? xcd_paired_tile(blockIdx.x, gridDim.x)
-                                           : (YA_BITS_TILE_MAP == 1 ? xcd_contiguous_tile(blockIdx.x, gridDim.x)
-                                                                    : (int)blockIdx.x);
-    const int s0 = tile * FB;
+    const int s0 = xcd_contiguous_tile(blockIdx.x, gridDim.x) * FB;
     const int s = s0 + threadIdx.x;
     bool active = s < n;
     const int c_lo = cube_id[s0];
@@ -953,19 +872,11 @@ __global__ __launch_bounds__(bits::BLOCK, bits::Waves<Pt>::value) void grid_forc
     float sum_friction = 0;
 
     int next_lo[3], next_hi[3], next_begin[3], next_end[3];
-#ifndef YA_BITS_PREFETCH_BOUNDS
-#define YA_BITS_PREFETCH_BOUNDS 1
-#endif
-#if YA_BITS_PREFETCH_BOUNDS
-    YA_ROW_BOUNDS(0)
-#endif
 #pragma unroll 1
     for (int plane = 0; plane < 3; plane++) {
         int wg_begin[3], v0[4], k_begin[3], k_end[3];
         v0[0] = 0;
-#if !YA_BITS_PREFETCH_BOUNDS
         YA_ROW_BOUNDS(plane)
-#endif
 #pragma unroll
         for (int r = 0; r < 3; r++) {
             wg_begin[r] = next_lo[r];
@@ -973,9 +884,6 @@ __global__ __launch_bounds__(bits::BLOCK, bits::Waves<Pt>::value) void grid_forc
             k_begin[r] = next_begin[r];
             k_end[r] = active ? next_end[r] : k_begin[r];
         }
-#if YA_BITS_PREFETCH_BOUNDS
-        if (plane < 2) { YA_ROW_BOUNDS(plane + 1) }
-#endif
         const int total = v0[3];
 
         for (int chunk = 0; chunk < total; chunk += CAP) {
@@ -986,9 +894,6 @@ __global__ __launch_bounds__(bits::BLOCK, bits::Waves<Pt>::value) void grid_forc
                 const int shift = v >= v0[2] ? wg_begin[2] - v0[2]
                                              : (v >= v0[1] ? wg_begin[1] - v0[1] : wg_begin[0]);
                 sh_e[t] = sorted[v + shift];
-#if YA_BITS_STAGE_V
-                sh_v[t] = sorted_v[v + shift];
-#endif
             }
             __syncthreads();
             // this lane's candidates of the three rows, as LDS indices clipped to the chunk
@@ -1002,9 +907,8 @@ __global__ __launch_bounds__(bits::BLOCK, bits::Waves<Pt>::value) void grid_forc
             const int bits_needed = (max(se[0] - sb[0], 0) + 3 & ~3) + (max(se[1] - sb[1], 0) + 3 & ~3) +
                                     (max(se[2] - sb[2], 0) + 3 & ~3);
             if (!__any(bits_needed > bits::PASS_BITS)) {
-                bits::pass<Pt, pw_int, pw_friction>(sh_e, staged_v, words, sb[0], se[0], sb[1], se[1],
-                    sb[2], se[2], shift[0], shift[1], shift[2], sorted_v, Xi, i, cut2, F, sum_v,
-                    sum_friction);
+                bits::pass<Pt, pw_int, pw_friction>(sh_e, words, sb[0], se[0], sb[1], se[1], sb[2],
+                    se[2], shift[0], shift[1], shift[2], sorted_v, Xi, i, cut2, F, sum_v, sum_friction);
             } else {
                 // dense rows: one pass per stretch of PASS_BITS candidates, rows in order
 #pragma unroll 1
@@ -1014,9 +918,8 @@ __global__ __launch_bounds__(bits::BLOCK, bits::Waves<Pt>::value) void grid_forc
                     const int rs = r == 0 ? shift[0] : (r == 1 ? shift[1] : shift[2]);
 #pragma unroll 1
                     for (int b = rb; __any(b < re); b += bits::PASS_BITS)
-                        bits::pass<Pt, pw_int, pw_friction>(sh_e, staged_v, words, b,
-                            min(re, b + bits::PASS_BITS), 0, 0, 0, 0, rs, 0, 0, sorted_v, Xi, i, cut2,
-                            F, sum_v, sum_friction);
+                        bits::pass<Pt, pw_int, pw_friction>(sh_e, words, b, min(re, b + bits::PASS_BITS),
+                            0, 0, 0, 0, rs, 0, 0, sorted_v, Xi, i, cut2, F, sum_v, sum_friction);
                 }
             }
         }
@@ -1026,7 +929,6 @@ __global__ __launch_bounds__(bits::BLOCK, bits::Waves<Pt>::value) void grid_forc
         if (d_dX_sorted) d_dX_sorted[s] = dX;  // for the sorted-space Euler stage
     }
 }
-
 
 #undef YA_ROW_BOUNDS
 

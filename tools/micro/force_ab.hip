@@ -2,7 +2,7 @@
 //   force_ab [cells] [warm take_steps] [rounds] [dist]
 // Builds the grid once on a state that `warm` take_steps have relaxed, then times
 // variant 1 (grid_force, byte FIFO) and variant 2 (grid_force_bits, compiled with this
-// executable's -DYA_BITS_* / -DYA_MASK_WORDS flags) in interleaved rounds with HIP events,
+// executable's -DYA_BITS_BLOCK / -DYA_BITS_POPS / -DYA_MASK_WORDS flags) in interleaved rounds with HIP events,
 // and compares their outputs (d_dX by id and d_dX in sorted order) bit for bit.
 // One JSON line per run; tools/micro/force_ab.sh builds and runs a set of configurations.
 #include <algorithm>
@@ -95,9 +95,9 @@ int main(int argc, char** argv)
         }
     printf("{\"tag\": \"%s\", \"base\": %d, \"test\": %d, \"cells\": %d, \"gs\": %d, \"dist\": %g, \"warm\": %d, \"rounds\": %d, "
            "\"fifo_us_median\": %.1f, \"fifo_us_min\": %.1f, \"bits_us_median\": %.1f, \"bits_us_min\": %.1f, "
-           "\"mismatches\": %ld, \"block\": %d, \"words\": %d, \"stage_v\": %d, \"waves\": %d}\n",
+           "\"mismatches\": %ld, \"block\": %d, \"words\": %d, \"pops\": %d}\n",
         AB_TAG, AB_BASE, AB_TEST, n, gs, dist, warm, rounds, median(us[0]), *std::min_element(us[0].begin(), us[0].end()),
         median(us[1]), *std::min_element(us[1].begin(), us[1].end()), mismatches, ya::bits::BLOCK,
-        ya::bits::WORDS, YA_BITS_STAGE_V, YA_BITS_WAVES);
+        ya::bits::WORDS, YA_BITS_POPS);
     return mismatches != 0;
 }
