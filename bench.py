@@ -115,8 +115,9 @@ def parse(argv=None):
                     help="attach HIP events to every this-many-th force-kernel launch (odd: both stages)")
     ap.add_argument("--sorted-pipeline", type=int, default=1,
                     help="1 = second Heun stage built from the sorted cells (default), 0 = from d_X1 (A/B)")
-    ap.add_argument("--graph", type=int, default=-1,
-                    help="1 = replay the step as a hipGraph, 0 = plain launches, -1 = the engine's choice")
+    ap.add_argument("--graph", type=int, default=0,
+                    help="Heun_solver::graph_steps: 1 = replay the step as a hipGraph, -1 = below 400 k "
+                         "cells only, 0 = plain launches (default)")
     args = ap.parse_args(argv)
     if args.model not in MODELS:
         ap.error(f"--model must be one of {sorted(MODELS)}")
@@ -294,7 +295,7 @@ def main(argv=None):
         if "grid" in args.model:
             sim.set_param("force_variant", args.force_variant)
             sim.set_param("sorted_pipeline", args.sorted_pipeline)
-            if args.graph >= 0:
+            if args.graph != 0:
                 sim.set_param("graph", args.graph)
         if args.model.startswith("sorting"):
             sim.set_param("n_cells", n_total)
@@ -329,13 +330,23 @@ def main(argv=None):
 
     advance(args.warmup)
     barrier()
-    # HIP events on every 5th launch of the force kernel (both stages alternate):
-    # a timed launch costs a few microseconds of stream time, see DESIGN.md section 6
-    sim.profile(True, every=args.time_every)
+    # The engine replays small systems' steps as a hipGraph (Heun_solver::graph_steps), which
+    # per-launch events would switch off: time those without events and measure the force
+    # kernel in a second, untimed pass of plain launches.
+    graph_mode = (not slab_path and "grid" in args.model and
+                  (args.graph == 1 or (args.graph == -1 and n_total < 400_000)))
+    if not graph_mode:
+        # HIP events on every 5th launch of the force kernel (both stages alternate):
+        # a timed launch costs a few microseconds of stream time, see DESIGN.md section 6
+        sim.profile(True, every=args.time_every)
     t0 = time.perf_counter()
     advance(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
+    if graph_mode:
+        sim.profile(True, every=1)
+        advance(min(args.steps, 10))
+        barrier()
     force_ms, launches = sim.profile_read()
     sim.profile(False)
     if not slab_path:
@@ -383,6 +394,7 @@ def main(argv=None):
                 "total_cells": n_total,
                 "grid_size": gs,
                 "cube_size": 1.0,
+                "step_replayed_as_hipgraph": bool(graph_mode),
                 "parallelism": "1 GPU" if world == 1 else
                                f"{world} z-slabs of one {n_total}-cell system, ghost exchange via "
                                + ("RCCL send/recv" if args.backend == "nccl" else

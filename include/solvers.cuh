@@ -197,6 +197,7 @@ public:
         stride = every > 0 ? every : 1;
         seen = 0;
     }
+    bool active() const { return enabled; }
     void next(hipEvent_t* start, hipEvent_t* stop)
     {
         *start = *stop = nullptr;
@@ -1251,6 +1252,8 @@ public:
         ya_free(d_fix);
         ya_free(d_fix_first);
         ya_free(d_workspace);
+        drop_graph();
+        if (capture_stream) (void)hipStreamDestroy(capture_stream);
     }
     Heun_solver(const Heun_solver&) = delete;
     void set_fixed() { fix_com = true; }
@@ -1265,8 +1268,41 @@ public:
         fix_com_z = true;
         fix_point = point_id;
     }
+    // Replaying the step as one hipGraph (Grid_solver without generic forces), opt-in:
+    // 1 = whenever possible, -1 = for systems below YA_GRAPH_MAX_CELLS cells, 0 (default) =
+    // never.  The graph is captured the second time the same step (functors, n, dt, fixed
+    // point, cube size, force kernel) is asked for and replayed while that stays so; a
+    // changing n (proliferation) simply keeps the plain launches.  Results are identical: the
+    // same kernels with the same arguments.  Measured on MI355X it buys nothing when the
+    // host queues launches from a C++ loop (a step of a 10^4-cell system is bound by the
+    // ~18 dependent kernels' own latencies, 0.19 ms either way); it is for hosts that
+    // cannot keep ~10^5 launches per second up.
+    int graph_steps = 0;
 
 protected:
+#ifndef YA_GRAPH_MAX_CELLS
+#define YA_GRAPH_MAX_CELLS 400000
+#endif
+    struct Step_key {
+        const void* functors = nullptr;
+        int n = -1;
+        float dt = 0, cube_size = 0;
+        int variant = 0, fix_mode = 0, fix_point = 0;
+        bool operator==(const Step_key& o) const
+        {
+            return functors == o.functors && n == o.n && dt == o.dt && cube_size == o.cube_size &&
+                   variant == o.variant && fix_mode == o.fix_mode && fix_point == o.fix_point;
+        }
+    };
+    Step_key graph_key, last_key;
+    hipGraphExec_t graph_exec = nullptr;
+    hipStream_t capture_stream = nullptr;
+    void drop_graph()
+    {
+        if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+        graph_exec = nullptr;
+        graph_key = Step_key{};
+    }
     static constexpr int n_floats = ya::N_floats<Pt>::value;
     Pt *d_X, *d_dX, *d_X1, *d_dX1;
     float3* d_old_v;
@@ -1293,12 +1329,12 @@ protected:
         float* mean_out = first ? d_mean_first : d_mean;
         float* fix_out = first ? d_fix_first : d_fix;
         if (mean) {  // solvers.cuh:241-249 / :266-268
-            YA_CHECK(ya_reduce_mean(d_rhs, n_floats, n, mean_out, d_workspace, nullptr));
+            YA_CHECK(ya_reduce_mean(d_rhs, n_floats, n, mean_out, d_workspace, this->stream));
             if (!point_xy) return mean_out;
-            ya::make_fix<Pt><<<1, 1>>>(2, mean_out, d_rhs + fix_point, fix_out);
+            ya::make_fix<Pt><<<1, 1, 0, this->stream>>>(2, mean_out, d_rhs + fix_point, fix_out);
             return fix_out;
         }
-        ya::make_fix<Pt><<<1, 1>>>(1, mean_out, d_rhs + fix_point, fix_out);  // :250-253
+        ya::make_fix<Pt><<<1, 1, 0, this->stream>>>(1, mean_out, d_rhs + fix_point, fix_out);  // :250-253
         return fix_out;
     }
 
@@ -1354,12 +1390,76 @@ protected:
                 n, dt, d_dX, d_fix_velocity, d_dX1, d_X, d_old_v);
     }
 
+    // Sorted-space pipeline (Grid_solver without generic forces): the predictor lives in
+    // the cube-sorted copy of the cells, so the second grid build gathers nothing and
+    // d_X1 is never materialised.  Same arithmetic, same results.
+    template<Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction>
+    void sorted_step(const int n, const float dt)
+    {
+        const int blocks = (n + ya::UPDATE_BLOCK - 1) / ya::UPDATE_BLOCK;
+        Computer<Pt>::template pwints<pw_int, pw_friction>(n, d_X, d_old_v, d_dX, false, n, true);
+        // this stage's fixed velocity has to outlive the next reduction
+        const float* fix = fix_velocity(n, d_dX, fix_com or fix_com_z, fix_com_z, true);
+        Computer<Pt>::predictor_in_sorted_space(n, dt, fix, n);
+        Computer<Pt>::template pwints_from_sorted<pw_int, pw_friction>(n, d_dX1, n, false);
+        const float* fix1 = fix_velocity(n, d_dX1, fix_com, false);
+        heun_step_raw<<<blocks, ya::UPDATE_BLOCK, 0, this->stream>>>(
+            n, dt, d_dX, fix, d_dX1, fix1, d_X, d_old_v);
+    }
+
+    template<Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction>
+    Step_key key_of(const int n, const float dt)
+    {
+        static const char functors_tag = 0;  // one per <pw_int, pw_friction>
+        Step_key k;
+        k.functors = &functors_tag;
+        k.n = n;
+        k.dt = dt;
+        k.cube_size = Computer<Pt>::step_cube_size();
+        k.variant = Computer<Pt>::step_variant();
+        k.fix_mode = (fix_com ? 1 : 0) | (fix_com_z ? 2 : 0);
+        k.fix_point = fix_point;
+        return k;
+    }
+
     template<Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction>
     void take_step(float dt, Generic_forces<Pt> gen_forces)
     {
         const bool sorted_path =
             Computer<Pt>::use_sorted_pipeline() && ya::is_no_gen_forces<Pt>(gen_forces);
         int n;
+        if (sorted_path && graph_steps != 0 && last_key.n > 0 && !Computer<Pt>::profiler.active() &&
+            (graph_steps > 0 || last_key.n < YA_GRAPH_MAX_CELLS)) {
+            // Small system: read n first (solvers.cuh:229), then replay / capture / launch.
+            n = get_d_n();
+            if (n <= 0) return;
+            const Step_key key = key_of<pw_int, pw_friction>(n, dt);
+            if (graph_exec && key == graph_key) {
+                YA_CHECK((int)hipGraphLaunch(graph_exec, nullptr));
+                return;
+            }
+            if (key == last_key && (graph_steps > 0 || n < YA_GRAPH_MAX_CELLS)) {
+                // the same step as last time: capture it (thread-local mode: other host
+                // threads of the model, e.g. one writing output, may keep using HIP)
+                drop_graph();
+                if (!capture_stream)
+                    YA_CHECK((int)hipStreamCreateWithFlags(&capture_stream, hipStreamNonBlocking));
+                YA_CHECK((int)hipStreamBeginCapture(capture_stream, hipStreamCaptureModeThreadLocal));
+                this->stream = capture_stream;
+                sorted_step<pw_int, pw_friction>(n, dt);
+                this->stream = nullptr;
+                hipGraph_t graph = nullptr;
+                YA_CHECK((int)hipStreamEndCapture(capture_stream, &graph));
+                YA_CHECK((int)hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0));
+                YA_CHECK((int)hipGraphDestroy(graph));
+                graph_key = key;
+                YA_CHECK((int)hipGraphLaunch(graph_exec, nullptr));
+                return;
+            }
+            last_key = key;
+            sorted_step<pw_int, pw_friction>(n, dt);
+            return;
+        }
         if (sorted_path) {
             // The reference reads n first (solvers.cuh:229) and so must we, model kernels
             // change it between steps; but the round trip is hidden behind the binning
@@ -1377,20 +1477,11 @@ protected:
         }
 
         if (sorted_path) {
-            // Sorted-space pipeline: the predictor lives in the cube-sorted copy of
-            // the cells, so the second grid build gathers nothing and d_X1 is never
-            // materialised.  Same arithmetic, same results.
-            const int blocks = (n + ya::UPDATE_BLOCK - 1) / ya::UPDATE_BLOCK;
-            Computer<Pt>::template pwints<pw_int, pw_friction>(n, d_X, d_old_v, d_dX, false, n, true);
-            // this stage's fixed velocity has to outlive the next reduction
-            const float* fix = fix_velocity(n, d_dX, fix_com or fix_com_z, fix_com_z, true);
-            Computer<Pt>::predictor_in_sorted_space(n, dt, fix, n);
-            Computer<Pt>::template pwints_from_sorted<pw_int, pw_friction>(n, d_dX1, n, false);
-            const float* fix1 = fix_velocity(n, d_dX1, fix_com, false);
-            heun_step_raw<<<blocks, ya::UPDATE_BLOCK>>>(
-                n, dt, d_dX, fix, d_dX1, fix1, d_X, d_old_v);
+            last_key = key_of<pw_int, pw_friction>(n, dt);
+            sorted_step<pw_int, pw_friction>(n, dt);
             return;
         }
+        last_key = Step_key{};
 
         // 1st stage
         stage_rhs<pw_int, pw_friction>(1, n, n, gen_forces);
@@ -1415,6 +1506,9 @@ public:
     bool use_sorted_pipeline() const { return false; }
 
 protected:
+    hipStream_t stream = nullptr;  // every launch of a step goes here (null = the default stream)
+    float step_cube_size() const { return 0; }
+    int step_variant() const { return 0; }
     void check_status() {}
     void begin_build(const Pt*, const int*, int) {}
     void cancel_build() {}
@@ -1477,10 +1571,10 @@ public:
     // Engine-side extras (not in the reference).
     template<typename Pt>
     void build_sorted(const int n, const Pt* d_X, const float3* d_old_v, const float cube_size,
-        ya::Entry<Pt>* d_sorted, float4* d_sorted_v)
+        ya::Entry<Pt>* d_sorted, float4* d_sorted_v, hipStream_t stream = nullptr)
     {
         YA_CHECK(ya_grid_build_sorted(handle, d_X, sizeof(Pt), d_old_v, n, cube_size, d_sorted,
-            sizeof(ya::Entry<Pt>), d_sorted_v, nullptr));
+            sizeof(ya::Entry<Pt>), d_sorted_v, stream));
     }
     // build_sorted in two halves: the first one reads the count on the device and can be
     // queued before the host has it (ya_grid_build_sorted_begin / _finish).
@@ -1500,10 +1594,11 @@ public:
     // from those entries themselves: nothing is gathered through point ids.
     template<typename Pt>
     void rebuild_sorted(const int n, const ya::Entry<Pt>* d_prev, const float4* d_prev_v,
-        const float cube_size, ya::Entry<Pt>* d_sorted, float4* d_sorted_v)
+        const float cube_size, ya::Entry<Pt>* d_sorted, float4* d_sorted_v,
+        hipStream_t stream = nullptr)
     {
         YA_CHECK(ya_grid_rebuild_sorted(handle, d_prev, sizeof(ya::Entry<Pt>), sizeof(Pt),
-            d_prev_v, n, cube_size, d_sorted, d_sorted_v, nullptr));
+            d_prev_v, n, cube_size, d_sorted, d_sorted_v, stream));
     }
     const int* offsets() const { return d_offs; }
     void check_status()
@@ -1565,6 +1660,9 @@ public:
     bool use_sorted_pipeline() const { return sorted_pipeline and force_variant != 0; }
 
 protected:
+    hipStream_t stream = nullptr;  // every launch of a step goes here (null = the default stream)
+    float step_cube_size() const { return cube_size; }
+    int step_variant() const { return force_variant; }
     Grid grid;
     ya::Entry<Pt>*d_sorted, *d_resorted;
     float4 *d_sorted_v, *d_resorted_v;
@@ -1577,22 +1675,30 @@ protected:
         const int blocks = (n + ya::FORCE_BLOCK - 1) / ya::FORCE_BLOCK;
         hipEvent_t start, stop;
         profiler.next(&start, &stop);
-        if (force_variant == 2)
-            hipExtLaunchKernelGGL((ya::grid_force_bits<Pt, pw_int, pw_friction>),
-                dim3((n + ya::bits::BLOCK - 1) / ya::bits::BLOCK), dim3(ya::bits::BLOCK), 0, nullptr,
-                start, stop, 0, n, d_cells, d_cells_v, (const int*)grid.d_cube_id, grid.offsets(),
-                grid.grid_size, grid.n_cubes, ya::cutoff_squared(cube_size), d_dX, has_gen, n_active,
-                d_dX_in_cell_order);
-        else if (force_variant == 0)
-            hipExtLaunchKernelGGL((ya::grid_force_direct<Pt, pw_int, pw_friction>), dim3(blocks),
-                dim3(ya::FORCE_BLOCK), 0, nullptr, start, stop, 0, n, d_cells, d_cells_v,
-                (const int*)grid.d_cube_id, grid.offsets(), grid.grid_size, grid.n_cubes,
-                cube_size, d_dX, has_gen, n_active);
-        else
-            hipExtLaunchKernelGGL((ya::grid_force<Pt, pw_int, pw_friction>), dim3(blocks),
-                dim3(ya::FORCE_BLOCK), 0, nullptr, start, stop, 0, n, d_cells, d_cells_v,
-                (const int*)grid.d_cube_id, grid.offsets(), grid.grid_size, grid.n_cubes,
-                ya::cutoff_squared(cube_size), d_dX, has_gen, n_active, d_dX_in_cell_order);
+        const float cut2 = ya::cutoff_squared(cube_size);
+        // a timed launch carries its events in the dispatch itself (ya::Profiler); an untimed
+        // one is a plain launch, which is also what a stream capture records
+#define YA_FORCE_LAUNCH(kernel_, grid_, block_, ...)                                          \
+    if (start)                                                                                \
+        hipExtLaunchKernelGGL((kernel_), dim3(grid_), dim3(block_), 0, stream, start, stop, 0, \
+            __VA_ARGS__);                                                                     \
+    else                                                                                      \
+        hipLaunchKernelGGL((kernel_), dim3(grid_), dim3(block_), 0, stream, __VA_ARGS__)
+        if (force_variant == 2) {
+            YA_FORCE_LAUNCH((ya::grid_force_bits<Pt, pw_int, pw_friction>),
+                (n + ya::bits::BLOCK - 1) / ya::bits::BLOCK, ya::bits::BLOCK, n, d_cells, d_cells_v,
+                (const int*)grid.d_cube_id, grid.offsets(), grid.grid_size, grid.n_cubes, cut2, d_dX,
+                has_gen, n_active, d_dX_in_cell_order);
+        } else if (force_variant == 0) {
+            YA_FORCE_LAUNCH((ya::grid_force_direct<Pt, pw_int, pw_friction>), blocks, ya::FORCE_BLOCK, n,
+                d_cells, d_cells_v, (const int*)grid.d_cube_id, grid.offsets(), grid.grid_size,
+                grid.n_cubes, cube_size, d_dX, has_gen, n_active);
+        } else {
+            YA_FORCE_LAUNCH((ya::grid_force<Pt, pw_int, pw_friction>), blocks, ya::FORCE_BLOCK, n, d_cells,
+                d_cells_v, (const int*)grid.d_cube_id, grid.offsets(), grid.grid_size, grid.n_cubes,
+                cut2, d_dX, has_gen, n_active, d_dX_in_cell_order);
+        }
+#undef YA_FORCE_LAUNCH
     }
     // The part of the first stage's grid build that can be queued before the host knows
     // n (Heun_solver::take_step); pwints then only finishes the build.
@@ -1610,7 +1716,7 @@ protected:
         if (build_begun)
             grid.build_sorted_finish(n, d_X, d_old_v, d_sorted, d_sorted_v);
         else
-            grid.build_sorted(n, d_X, d_old_v, cube_size, d_sorted, d_sorted_v);
+            grid.build_sorted(n, d_X, d_old_v, cube_size, d_sorted, d_sorted_v, stream);
         build_begun = false;
         forces<pw_int, pw_friction>(n, d_sorted, d_sorted_v, d_dX, has_gen, n_active,
             keep_sorted ? d_dX_sorted : nullptr);
@@ -1620,19 +1726,19 @@ protected:
     void predictor_in_sorted_space(
         const int n, const float dt, const float* d_fix, const int n_active)
     {
-        euler_step_sorted<<<(n + ya::UPDATE_BLOCK - 1) / ya::UPDATE_BLOCK, ya::UPDATE_BLOCK>>>(
+        euler_step_sorted<<<(n + ya::UPDATE_BLOCK - 1) / ya::UPDATE_BLOCK, ya::UPDATE_BLOCK, 0, stream>>>(
             n, dt, d_fix, d_dX_sorted, d_sorted, n_active);
     }
     void ghosts_in_sorted_space(const int n, const int n_active, const Pt* d_X1)
     {
         if (n_active >= n) return;
-        ghosts_into_sorted<<<(n + ya::UPDATE_BLOCK - 1) / ya::UPDATE_BLOCK, ya::UPDATE_BLOCK>>>(
+        ghosts_into_sorted<<<(n + ya::UPDATE_BLOCK - 1) / ya::UPDATE_BLOCK, ya::UPDATE_BLOCK, 0, stream>>>(
             n, n_active, d_X1, d_sorted);
     }
     template<Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction>
     void pwints_from_sorted(const int n, Pt* d_dX, const int n_active, const bool has_gen)
     {
-        grid.rebuild_sorted(n, d_sorted, d_sorted_v, cube_size, d_resorted, d_resorted_v);
+        grid.rebuild_sorted(n, d_sorted, d_sorted_v, cube_size, d_resorted, d_resorted_v, stream);
         forces<pw_int, pw_friction>(n, d_resorted, d_resorted_v, d_dX, has_gen, n_active, nullptr);
     }
 };

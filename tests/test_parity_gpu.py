@@ -271,3 +271,31 @@ def test_dense_po_cell_bit_exact(oracle, device):
     (Xo, vo, _), (Xd, vd, _) = run_both(oracle, device, "relu_po_grid", n, 50, 1.0, 0.2, 3, 0.001, 2)
     assert np.array_equal(Xo.view(np.uint32), Xd.view(np.uint32))
     assert np.array_equal(vo.view(np.uint32), vd.view(np.uint32))
+
+
+def test_graph_replay_is_the_same_step(oracle, device):
+    """Heun_solver::graph_steps: the step replayed as one hipGraph (captured the second time
+    the same step is asked for) gives bit-identical positions, velocities and grid arrays to
+    plain launches and to the oracle -- also across a change of dt (new capture), of the
+    fixed point, and for a 24-byte point."""
+    for model, n, dts in (("springs_grid", 20000, (0.001, 0.001, 0.001, 0.001, 0.002, 0.002, 0.002)),
+                          ("relu_po_grid", 6000, (0.05,) * 6)):
+        res = []
+        for mode in ("oracle", 0, 1, -1):
+            lib = oracle if mode == "oracle" else device
+            with Solution(model, n, 50, 1.0, lib=lib) as s:
+                if mode == "oracle":
+                    s.set_reduce_order(1)
+                else:
+                    s.set_param("graph", mode)
+                s.random_sphere(0.5, 9)
+                for k, dt in enumerate(dts):
+                    if k == 3:
+                        s.set_fixed(7)
+                    s.take_step(dt, 1)
+                res.append((s.positions(), s.old_v(), s.grid()))
+        for X, v, g in res[1:]:
+            assert np.array_equal(res[0][0].view(np.uint32), X.view(np.uint32)), model
+            assert np.array_equal(res[0][1].view(np.uint32), v.view(np.uint32)), model
+            for a, b in zip(res[0][2], g):
+                assert np.array_equal(a[:n] if len(a) == n else a, b[:n] if len(b) == n else b)
