@@ -111,10 +111,17 @@ def parse(argv=None):
                     help="torch.distributed backend for N > 1 / --slab: nccl (= RCCL), or gloo with "
                          "YALLA_BENCH_DEVICE=0 to rehearse the N-rank path on one GPU (RCCL refuses "
                          "two ranks per GPU; messages are then staged through the host)")
+    ap.add_argument("--sequencing", default="native", choices=["native", "python"],
+                    help="z-slab path: the step sequenced in C++ (ya_slab_step; with --backend nccl the "
+                         "messages go through libyalla_hip.so's own RCCL communicator and torch.distributed "
+                         "is not used at all) or by yalla_amd/slab.py over torch.distributed (A/B)")
     ap.add_argument("--time-every", type=int, default=5,
                     help="attach HIP events to every this-many-th force-kernel launch (odd: both stages)")
     ap.add_argument("--sorted-pipeline", type=int, default=1,
                     help="1 = second Heun stage built from the sorted cells (default), 0 = from d_X1 (A/B)")
+    ap.add_argument("--links-per-cell", type=int, default=3,
+                    help="springs_links_grid: links from every cell to this many nearest neighbours "
+                         "(protrusion-like load for Links::link_forces)")
     ap.add_argument("--graph", type=int, default=0,
                     help="Heun_solver::graph_steps: 1 = replay the step as a hipGraph, -1 = below 400 k "
                          "cells only, 0 = plain launches (default)")
@@ -268,7 +275,9 @@ def main(argv=None):
         sys.exit(f"bench.py: rank {rank} wants GPU {local_rank}, but only {torch.cuda.device_count()} "
                  "are visible (one process per GPU)")
     torch.cuda.set_device(local_rank)
-    if slab_path:
+    native_rccl = slab_path and args.sequencing == "native" and args.backend == "nccl"
+    use_torch_dist = slab_path and not native_rccl
+    if use_torch_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
@@ -284,10 +293,31 @@ def main(argv=None):
     gs = args.grid_size or grid_size_for(n_total, args.dist)
     dt = args.dt
 
+    native_comm = None
+    if native_rccl:
+        from yalla_amd import slab as slab_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        native_comm = slab_mod.NativeComm(port_offset=1)   # RCCL communicator of libyalla_hip.so
+        assert (native_comm.rank, native_comm.world) == (rank, world)
+
     def barrier():
-        if world > 1:
+        torch.cuda.synchronize()
+        if native_comm is not None:
+            native_comm.barrier()
+        elif world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def reduce_over_ranks(value, take_max=False):
+        if native_comm is not None:
+            return native_comm.allreduce_host([float(value)], take_max)[0]
+        if world == 1:
+            return float(value)
+        t = torch.tensor([float(value)], dtype=torch.float64,
+                         device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX if take_max else dist.ReduceOp.SUM)
+        return float(t.item())
 
     if not slab_path:
         sim = Solution(args.model, n_total, gs, 1.0)
@@ -299,6 +329,18 @@ def main(argv=None):
                 sim.set_param("graph", args.graph)
         if args.model.startswith("sorting"):
             sim.set_param("n_cells", n_total)
+        n_links = 0
+        if args.model == "springs_links_grid" and args.links_per_cell > 0:
+            # every cell linked to its k nearest neighbours (as the protrusions of
+            # examples/intercalation.cu:32-68 link nearby cells), fixed for the run
+            import numpy as np
+            from scipy.spatial import cKDTree
+            X = sim.h_X[:n_total].copy()
+            _, idx = cKDTree(X).query(X, k=args.links_per_cell + 1)
+            pairs = np.stack([np.repeat(np.arange(n_total), args.links_per_cell),
+                              idx[:, 1:].reshape(-1)], axis=1).astype(np.int32)
+            sim.set_links(pairs, 0.2)
+            n_links = len(pairs)
 
         def advance(k):
             sim.take_step(dt, k)
@@ -313,20 +355,33 @@ def main(argv=None):
             whole.random_sphere(args.dist, 42)
             X0 = whole.h_X[:n_total].copy()
         bounds = slab_mod.slab_bounds(X0[:, 2], world)
+        native_step = args.sequencing == "native"
         my_slab = slab_mod.Slab("springs_grid", X0, rank, world, bounds, gs, cube_size=1.0,
-                                device=f"cuda:{local_rank}")
+                                device=f"cuda:{local_rank}", python_buffers=not native_step,
+                                global_ids=False)  # spring only compares i with j
         del X0
         sim = my_slab.sim
         sim.set_param("force_variant", args.force_variant)
-        comm = slab_mod.DistComm()
+        if native_rccl:
+            my_slab.setup_native_step(comm=native_comm)
+        elif native_step:
+            my_slab.setup_native_step(transport=slab_mod.CallbackTransport(device_memory=True))
+        else:
+            comm = slab_mod.DistComm()
 
         step_no = [0]
+
+        def slab_step(migrate):
+            if native_step:
+                my_slab.step_native(dt, migrate)
+            else:
+                slab_mod.step([my_slab], comm, dt, migrate=migrate)
 
         def advance(k):
             # cells move ~1e-2 per step here; the ghost layer tolerates 0.25 of stray
             for _ in range(k):
                 step_no[0] += 1
-                slab_mod.step([my_slab], comm, dt, migrate=step_no[0] % args.migrate_every == 0)
+                slab_step(step_no[0] % args.migrate_every == 0)
 
     advance(args.warmup)
     barrier()
@@ -353,17 +408,11 @@ def main(argv=None):
         assert sim.get_d_n() == n_total
         n_force = n_total
     else:
-        slab_mod.step([my_slab], comm, dt, migrate=True)  # untimed: settle ownership, then count
+        slab_step(True)  # untimed: settle ownership, then count
         n_force = my_slab.n_own()   # cells a force launch computes (ghost cells get none)
-        counts = torch.tensor([n_force], dtype=torch.int64,
-                              device="cuda" if args.backend == "nccl" else "cpu")
-        dist.all_reduce(counts)
-        assert int(counts.item()) == n_total, "cells were lost or duplicated in migration"
+        assert int(reduce_over_ranks(n_force)) == n_total, "cells were lost or duplicated in migration"
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed = reduce_over_ranks(elapsed, take_max=True)
 
     if rank == 0:
         value = n_total * args.steps / elapsed
@@ -395,9 +444,13 @@ def main(argv=None):
                 "grid_size": gs,
                 "cube_size": 1.0,
                 "step_replayed_as_hipgraph": bool(graph_mode),
+                "links": n_links if not slab_path else 0,
                 "parallelism": "1 GPU" if world == 1 else
-                               f"{world} z-slabs of one {n_total}-cell system, ghost exchange via "
-                               + ("RCCL send/recv" if args.backend == "nccl" else
+                               f"{world} z-slabs of one {n_total}-cell system, step sequenced "
+                               + ("in C++ (ya_slab_step)" if args.sequencing == "native" else "by yalla_amd/slab.py")
+                               + ", ghost exchange via "
+                               + (("RCCL send/recv (libyalla_hip.so's communicator)" if native_rccl else
+                                   "RCCL send/recv (torch.distributed)") if args.backend == "nccl" else
                                   f"{args.backend} send/recv staged through the host (rehearsal mode)"),
             },
             "roofline": {
@@ -436,7 +489,9 @@ def main(argv=None):
         os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)
-    if slab_path:
+    if native_comm is not None:
+        native_comm.close()
+    if use_torch_dist:
         dist.destroy_process_group()
 
 

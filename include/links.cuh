@@ -4,9 +4,9 @@
 // copy_to_*), Link_force<Pt>, linear_force, link_forces (two overloads).
 //
 // MI355X notes: 256-thread workgroups (the reference launches half-empty
-// 32-thread blocks), the link count is read from the device once per call
-// instead of twice, and the default force issues hardware fp32 atomics
-// (global_atomic_add_f32) rather than compare-and-swap loops.
+// 32-thread blocks), the link count is read by the kernel from device memory
+// (no host round trip per call), and the default force issues hardware fp32
+// atomics (global_atomic_add_f32) rather than compare-and-swap loops.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -14,9 +14,14 @@
 
 #include <assert.h>
 #include <stdlib.h>
+#include <string.h>
 #include <time.h>
 
+#include <cstring>
 #include <functional>
+#include <type_traits>
+
+#include <rocprim/device/device_radix_sort.hpp>
 
 #include "cudebug.cuh"
 #include "utils.cuh"
@@ -26,6 +31,31 @@
 struct Link {
     int a, b;
 };
+
+namespace ya {
+// Buffers of the atomics-free link_forces path (below), owned by a Links object and sized
+// for its n_max slots on first use.
+struct Link_scratch {
+    float3* d_force = nullptr;                          // force of every link slot
+    unsigned *d_key = nullptr, *d_key_sorted = nullptr;  // endpoint cell of entry 2i (a), 2i + 1 (b)
+    unsigned *d_entry = nullptr, *d_entry_sorted = nullptr;
+    void* d_temp = nullptr;
+    size_t temp_bytes = 0;
+    void release()
+    {
+        ya_free(d_force);
+        ya_free(d_key);
+        ya_free(d_key_sorted);
+        ya_free(d_entry);
+        ya_free(d_entry_sorted);
+        ya_free(d_temp);
+        d_force = nullptr;
+        d_key = d_key_sorted = d_entry = d_entry_sorted = nullptr;
+        d_temp = nullptr;
+        temp_bytes = 0;
+    }
+};
+}  // namespace ya
 
 using Check_link = std::function<bool(int a, int b)>;
 
@@ -60,8 +90,10 @@ public:
         ya_free(d_link);
         ya_free(d_n);
         ya_free(d_state);
+        scratch.release();
     }
     Links(const Links&) = delete;
+    ya::Link_scratch scratch;  // engine-private (not in the reference)
     void set_d_n(int n)
     {
         assert(n <= n_max);
@@ -121,13 +153,18 @@ __device__ void linear_force(const Pt* __restrict__ d_X, const int a, const int 
     unsafeAtomicAdd(&d_dX[b].z, fz);
 }
 
-// One thread per link; inert links (a == b) are skipped (links.cuh:113-125).
+// One thread per link slot; inert links (a == b) are skipped (links.cuh:113-125).  The
+// number of links in use is read from links.d_n ON THE DEVICE (the launch covers n_max
+// slots): the reference's two blocking 4-byte reads per call (links.cuh:130-133) cost more
+// than the kernel itself, and model kernels may change *d_n right before.
 template<typename Pt, Link_force<Pt> force>
 __global__ __launch_bounds__(256) void link(const Pt* __restrict__ d_X, Pt* d_dX,
-    const Link* __restrict__ d_link, int n_links, float strength)
+    const Link* __restrict__ d_link, const int* __restrict__ d_n_links, int n_max, float strength)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_links) return;
+    const int n_links = *d_n_links;
+    D_ASSERT(n_links <= n_max);
+    if (i >= n_links || i >= n_max) return;
 
     const Link l = d_link[i];
     if (l.a == l.b) return;
@@ -135,18 +172,146 @@ __global__ __launch_bounds__(256) void link(const Pt* __restrict__ d_X, Pt* d_dX
     force(d_X, l.a, l.b, strength, d_dX);
 }
 
-template<typename Pt, Link_force<Pt> force>
-void link_forces(Links& links, const Pt* __restrict__ d_X, Pt* d_dX)
+// ---- linear_force without atomics --------------------------------------------------
+// On MI355X a floating-point atomic on global memory is served by the memory side of the
+// fabric, not by an XCD's L2 (eight L2s that are not coherent with each other): measured,
+// the one-thread-per-link kernel above sustains ~2 x 10^10 atomics per second -- 91 us for
+// 300 000 links, more than the whole grid force kernel of the 100 000 cells they connect.
+// For the default force the engine therefore does a segmented sum instead:
+//   1. link_linear_eval: one thread per link slot computes the link's force once and emits
+//      two (cell, entry) pairs, entry 2i for endpoint a (gets -f) and 2i + 1 for b (gets +f);
+//      inert or unused slots emit a key that sorts last;
+//   2. a stable radix sort of the pairs by cell (rocPRIM, 24 key bits);
+//   3. link_linear_apply: the first entry of every cell's segment sums the segment in sorted
+//      (= link slot) order and adds it to d_dX with a plain store.  Segments are cut every
+//      256 entries so that a hub cell cannot serialise a thread; only pieces of such cut
+//      segments use atomics.
+// No host round trip and results that repeat run to run (the atomics' order does not).
+// Used from YA_LINKS_SEGMENTED_MIN link slots up (see there).  Custom Link_force functors
+// do their own atomics on d_dX and keep the one-thread-per-link kernel.
+namespace ya {
+constexpr unsigned LINK_DEAD_KEY = 0xFFFFFFu;  // cells are numbered below 2^24 - 1
+constexpr int LINK_KEY_BITS = 24;
+constexpr int LINK_SEGMENT_CUT = 256;
+
+template<typename Pt>
+__global__ __launch_bounds__(256) void link_linear_eval(const Pt* __restrict__ d_X,
+    const Link* __restrict__ d_link, const int* __restrict__ d_n_links, const int n_max,
+    const float strength, float3* __restrict__ force, unsigned* __restrict__ key,
+    unsigned* __restrict__ entry)
 {
-    const int n_links = links.get_d_n();
-    if (n_links <= 0) return;
-    link<Pt, force><<<(n_links + 255) / 256, 256>>>(
-        d_X, d_dX, links.d_link, n_links, links.strength);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_max) return;
+    const int n_links = *d_n_links;
+    D_ASSERT(n_links <= n_max);
+    Link l{0, 0};
+    if (i < n_links) l = d_link[i];
+    unsigned key_a = LINK_DEAD_KEY, key_b = LINK_DEAD_KEY;
+    if (l.a != l.b) {
+        D_ASSERT((unsigned)l.a < LINK_DEAD_KEY && (unsigned)l.b < LINK_DEAD_KEY);
+        const Pt r = d_X[l.a] - d_X[l.b];
+        const float dist = sqrtf(fmaf(r.z, r.z, fmaf(r.y, r.y, r.x * r.x)));
+        force[i] = float3{strength * r.x / dist, strength * r.y / dist, strength * r.z / dist};
+        key_a = (unsigned)l.a;
+        key_b = (unsigned)l.b;
+    }
+    key[2 * i] = key_a;
+    key[2 * i + 1] = key_b;
+    entry[2 * i] = 2u * i;
+    entry[2 * i + 1] = 2u * i + 1u;
 }
 
 template<typename Pt>
+__global__ __launch_bounds__(256) void link_linear_apply(const unsigned* __restrict__ key,
+    const unsigned* __restrict__ entry, const float3* __restrict__ force, const int n_entries,
+    Pt* d_dX)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_entries) return;
+    const unsigned cell = key[t];
+    if (cell == LINK_DEAD_KEY) return;
+    const bool continues = t > 0 && key[t - 1] == cell;   // the segment began before t
+    if (continues && t % LINK_SEGMENT_CUT != 0) return;   // neither a segment head nor a cut
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    int u = t;
+    do {
+        const unsigned e = entry[u];
+        const float3 f = force[e >> 1];
+        const float sign = (e & 1u) ? 1.f : -1.f;  // endpoint a: dX -= f, endpoint b: dX += f
+        sx += sign * f.x;
+        sy += sign * f.y;
+        sz += sign * f.z;
+        u++;
+    } while (u < n_entries && key[u] == cell && u % LINK_SEGMENT_CUT != 0);
+    const bool cut_after = u < n_entries && key[u] == cell;
+    if (continues || cut_after) {  // a piece of a segment longer than the cut
+        unsafeAtomicAdd(&d_dX[cell].x, sx);
+        unsafeAtomicAdd(&d_dX[cell].y, sy);
+        unsafeAtomicAdd(&d_dX[cell].z, sz);
+    } else {
+        d_dX[cell].x += sx;
+        d_dX[cell].y += sy;
+        d_dX[cell].z += sz;
+    }
+}
+
+template<typename Pt>
+void link_forces_segmented(Links& links, const Pt* __restrict__ d_X, Pt* d_dX)
+{
+    Link_scratch& s = links.scratch;
+    const int n_entries = 2 * links.n_max;
+    if (!s.d_force) {
+        const size_t words = (size_t)n_entries * sizeof(unsigned);
+        YA_CHECK(ya_malloc((void**)&s.d_force, (size_t)links.n_max * sizeof(float3)));
+        YA_CHECK(ya_malloc((void**)&s.d_key, words));
+        YA_CHECK(ya_malloc((void**)&s.d_key_sorted, words));
+        YA_CHECK(ya_malloc((void**)&s.d_entry, words));
+        YA_CHECK(ya_malloc((void**)&s.d_entry_sorted, words));
+        YA_CHECK((int)rocprim::radix_sort_pairs(nullptr, s.temp_bytes, s.d_key, s.d_key_sorted, s.d_entry,
+            s.d_entry_sorted, (size_t)n_entries, 0, LINK_KEY_BITS, (hipStream_t) nullptr));
+        YA_CHECK(ya_malloc(&s.d_temp, s.temp_bytes > 0 ? s.temp_bytes : 16));
+    }
+    const int blocks = (links.n_max + 255) / 256;
+    link_linear_eval<Pt><<<blocks, 256>>>(
+        d_X, links.d_link, links.d_n, links.n_max, links.strength, s.d_force, s.d_key, s.d_entry);
+    YA_CHECK((int)rocprim::radix_sort_pairs(s.d_temp, s.temp_bytes, s.d_key, s.d_key_sorted, s.d_entry,
+        s.d_entry_sorted, (size_t)n_entries, 0, LINK_KEY_BITS, (hipStream_t) nullptr));
+    link_linear_apply<Pt><<<(n_entries + 255) / 256, 256>>>(
+        s.d_key_sorted, s.d_entry_sorted, s.d_force, n_entries, d_dX);
+}
+}  // namespace ya
+
+// The sort is ~10 launches of rocPRIM kernels: measured on MI355X the segmented path is
+// slower than the atomics below ~10^6 link slots (0.53 vs 0.39 ms per step at 3 x 10^5
+// links) and 1.65 x faster at 3 x 10^6 (1.51 vs 2.49 ms per step).
+#ifndef YA_LINKS_SEGMENTED_MIN
+#define YA_LINKS_SEGMENTED_MIN 1000000
+#endif
+namespace ya {
+// the threshold at run time (tests force either path)
+inline int& links_segmented_min()
+{
+    static int slots = YA_LINKS_SEGMENTED_MIN;
+    return slots;
+}
+}  // namespace ya
+
+template<typename Pt, Link_force<Pt> force>
 void link_forces(Links& links, const Pt* __restrict__ d_X, Pt* d_dX)
 {
+    if (links.n_max <= 0) return;
+    link<Pt, force><<<(links.n_max + 255) / 256, 256>>>(
+        d_X, d_dX, links.d_link, links.d_n, links.n_max, links.strength);
+}
+
+// The default force (links.cuh:135-140): segmented sum for large link sets, atomics otherwise.
+template<typename Pt>
+void link_forces(Links& links, const Pt* __restrict__ d_X, Pt* d_dX)
+{
+    if (links.n_max >= ya::links_segmented_min()) {
+        ya::link_forces_segmented<Pt>(links, d_X, d_dX);
+        return;
+    }
     link_forces<Pt, linear_force<Pt>>(links, d_X, d_dX);
 }
 

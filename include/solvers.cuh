@@ -338,7 +338,7 @@ __global__ __launch_bounds__(FORCE_BLOCK) void grid_force_direct(const int n,
     const Entry<Pt>* __restrict__ sorted, const float4* __restrict__ sorted_v,
     const int* __restrict__ cube_id, const int* __restrict__ offs, const int gs,
     const int n_cubes, const float cube_size, Pt* __restrict__ d_dX, const bool has_gen,
-    const int n_active)
+    const int n_active, const int* __restrict__ global_id)
 {
     const int s = blockIdx.x * FORCE_BLOCK + threadIdx.x;
     if (s >= n) return;
@@ -347,6 +347,8 @@ __global__ __launch_bounds__(FORCE_BLOCK) void grid_force_direct(const int n,
     const Pt Xi = self.X;
     const int i = self.id;
     if (i >= n_active) return;  // ghost cell of a slab decomposition: no force needed
+    // functors see GLOBAL ids in a slab decomposition (they index per-cell model arrays)
+    const int gi = global_id ? global_id[i] : i;
     const int c = cube_id[s];
     Pt F = ya::zero<Pt>();
     float3 sum_v{0.f, 0.f, 0.f};
@@ -364,9 +366,9 @@ __global__ __launch_bounds__(FORCE_BLOCK) void grid_force_direct(const int n,
             float dist = dist3(r.x, r.y, r.z);
             if (dist >= cube_size) continue;
 
-            const int j = other.id;
-            F += pw_int(Xi, r, dist, i, j);
-            float friction = pw_friction(Xi, r, dist, i, j);
+            const int j = global_id ? global_id[other.id] : other.id;
+            F += pw_int(Xi, r, dist, gi, j);
+            float friction = pw_friction(Xi, r, dist, gi, j);
             sum_friction += friction;
             if (friction != 0) {
                 float4 v = sorted_v[k];
@@ -467,7 +469,7 @@ __global__ __launch_bounds__(FORCE_BLOCK) void grid_force(const int n,
     const Entry<Pt>* __restrict__ sorted, const float4* __restrict__ sorted_v,
     const int* __restrict__ cube_id, const int* __restrict__ offs, const int gs,
     const int n_cubes, const float cut2, Pt* __restrict__ d_dX, const bool has_gen,
-    const int n_active, Pt* __restrict__ d_dX_sorted)
+    const int n_active, Pt* __restrict__ d_dX_sorted, const int* __restrict__ global_id)
 {
     constexpr int CAP = Stage_cells<Pt>::value;
     __shared__ __attribute__((aligned(16))) Entry<Pt> sh_e[CAP + 8];  // slack: phase 1 reads whole groups
@@ -503,6 +505,7 @@ __global__ __launch_bounds__(FORCE_BLOCK) void grid_force(const int n,
         active = i < n_active;  // ghost cells of a slab decomposition get no force
     }
     if (!__syncthreads_or(active)) return;  // a workgroup of ghosts only
+    const int gi = global_id && active ? global_id[i] : i;  // what functors see (slab mode: global ids)
     Pt F = ya::zero<Pt>();
     float3 sum_v{0.f, 0.f, 0.f};
     float sum_friction = 0;
@@ -638,9 +641,9 @@ __global__ __launch_bounds__(FORCE_BLOCK) void grid_force(const int n,
                     const float4 v = sorted_v[slot];
                     Pt r = Xi - other.X;
                     float dist = dist3(r.x, r.y, r.z);
-                    const int j = other.id;
-                    F += pw_int(Xi, r, dist, i, j);
-                    float friction = pw_friction(Xi, r, dist, i, j);
+                    const int j = global_id ? global_id[other.id] : other.id;
+                    F += pw_int(Xi, r, dist, gi, j);
+                    float friction = pw_friction(Xi, r, dist, gi, j);
                     sum_friction += friction;
                     if (friction != 0) {
                         sum_v.x += friction * v.x;
@@ -738,7 +741,8 @@ template<typename Pt, Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_
 __device__ __forceinline__ void pass(const Entry<Pt>* __restrict__ sh_e, Lds_word* const words,
     const int b0, const int e0, const int b1, const int e1, const int b2, const int e2,
     const int shift0, const int shift1, const int shift2, const float4* __restrict__ sorted_v,
-    const Pt& Xi, const int i, const float cut2, Pt& F, float3& sum_v, float& sum_friction)
+    const Pt& Xi, const int i, const float cut2, Pt& F, float3& sum_v, float& sum_friction,
+    const int* __restrict__ global_id)
 {
     // ---- phase 1 ----
     unsigned m = 0;
@@ -795,7 +799,7 @@ __device__ __forceinline__ void pass(const Entry<Pt>* __restrict__ sh_e, Lds_wor
     {                                                                                  \
         Pt r = Xi - other_.X;                                                          \
         float dist = dist3(r.x, r.y, r.z);                                             \
-        const int j = other_.id;                                                       \
+        const int j = global_id ? global_id[other_.id] : other_.id;                    \
         F += pw_int(Xi, r, dist, i, j);                                                \
         float friction = pw_friction(Xi, r, dist, i, j);                               \
         sum_friction += friction;                                                      \
@@ -844,7 +848,7 @@ __global__ __launch_bounds__(bits::BLOCK) void grid_force_bits(const int n,
     const Entry<Pt>* __restrict__ sorted, const float4* __restrict__ sorted_v,
     const int* __restrict__ cube_id, const int* __restrict__ offs, const int gs,
     const int n_cubes, const float cut2, Pt* __restrict__ d_dX, const bool has_gen,
-    const int n_active, Pt* __restrict__ d_dX_sorted)
+    const int n_active, Pt* __restrict__ d_dX_sorted, const int* __restrict__ global_id)
 {
     constexpr int FB = bits::BLOCK;
     constexpr int CAP = bits::Stage<Pt>::value;
@@ -868,6 +872,8 @@ __global__ __launch_bounds__(bits::BLOCK) void grid_force_bits(const int n,
         active = i < n_active;  // ghost cells of a slab decomposition get no force
     }
     if (!__syncthreads_or(active)) return;  // a workgroup of ghosts only
+    // functors see GLOBAL ids in a slab decomposition (they index per-cell model arrays)
+    const int gi = global_id && active ? global_id[i] : i;
     Pt F = ya::zero<Pt>();
     float3 sum_v{0.f, 0.f, 0.f};
     float sum_friction = 0;
@@ -909,7 +915,8 @@ __global__ __launch_bounds__(bits::BLOCK) void grid_force_bits(const int n,
                                     (max(se[2] - sb[2], 0) + 3 & ~3);
             if (!__any(bits_needed > bits::PASS_BITS)) {
                 bits::pass<Pt, pw_int, pw_friction>(sh_e, words, sb[0], se[0], sb[1], se[1], sb[2],
-                    se[2], shift[0], shift[1], shift[2], sorted_v, Xi, i, cut2, F, sum_v, sum_friction);
+                    se[2], shift[0], shift[1], shift[2], sorted_v, Xi, gi, cut2, F, sum_v, sum_friction,
+                    global_id);
             } else {
                 // dense rows: one pass per stretch of PASS_BITS candidates, rows in order
 #pragma unroll 1
@@ -920,7 +927,7 @@ __global__ __launch_bounds__(bits::BLOCK) void grid_force_bits(const int n,
 #pragma unroll 1
                     for (int b = rb; __any(b < re); b += bits::PASS_BITS)
                         bits::pass<Pt, pw_int, pw_friction>(sh_e, words, b, min(re, b + bits::PASS_BITS),
-                            0, 0, 0, 0, rs, 0, 0, sorted_v, Xi, i, cut2, F, sum_v, sum_friction);
+                            0, 0, 0, 0, rs, 0, 0, sorted_v, Xi, gi, cut2, F, sum_v, sum_friction, global_id);
                 }
             }
         }
@@ -1657,6 +1664,9 @@ public:
     }
     Grid_computer(const Grid_computer&) = delete;
     bool sorted_pipeline = true;  // false = both stages through d_X / d_X1 (A/B)
+    // z-slab decomposition: local cell index -> global id (own cells, then ghosts); pairwise
+    // functors are then called with global (i, j).  NULL (default): local = global.
+    const int* d_global_id = nullptr;
     bool use_sorted_pipeline() const { return sorted_pipeline and force_variant != 0; }
 
 protected:
@@ -1688,15 +1698,15 @@ protected:
             YA_FORCE_LAUNCH((ya::grid_force_bits<Pt, pw_int, pw_friction>),
                 (n + ya::bits::BLOCK - 1) / ya::bits::BLOCK, ya::bits::BLOCK, n, d_cells, d_cells_v,
                 (const int*)grid.d_cube_id, grid.offsets(), grid.grid_size, grid.n_cubes, cut2, d_dX,
-                has_gen, n_active, d_dX_in_cell_order);
+                has_gen, n_active, d_dX_in_cell_order, (const int*)d_global_id);
         } else if (force_variant == 0) {
             YA_FORCE_LAUNCH((ya::grid_force_direct<Pt, pw_int, pw_friction>), blocks, ya::FORCE_BLOCK, n,
                 d_cells, d_cells_v, (const int*)grid.d_cube_id, grid.offsets(), grid.grid_size,
-                grid.n_cubes, cube_size, d_dX, has_gen, n_active);
+                grid.n_cubes, cube_size, d_dX, has_gen, n_active, (const int*)d_global_id);
         } else {
             YA_FORCE_LAUNCH((ya::grid_force<Pt, pw_int, pw_friction>), blocks, ya::FORCE_BLOCK, n, d_cells,
                 d_cells_v, (const int*)grid.d_cube_id, grid.offsets(), grid.grid_size, grid.n_cubes,
-                cut2, d_dX, has_gen, n_active, d_dX_in_cell_order);
+                cut2, d_dX, has_gen, n_active, d_dX_in_cell_order, (const int*)d_global_id);
         }
 #undef YA_FORCE_LAUNCH
     }

@@ -29,7 +29,7 @@ extern "C" {
 /* The libraries are built with -fvisibility=hidden; only this C ABI is exported. */
 #pragma GCC visibility push(default)
 
-#define YA_ABI_VERSION 4
+#define YA_ABI_VERSION 5
 
 /* Status bits reported by ya_grid_status(). */
 #define YA_STATUS_OUT_OF_GRID 1 /* a cell's cube id fell outside [0, n_cubes):
@@ -169,6 +169,40 @@ int ya_gather_rows(const void* d_src, size_t row_bytes, const int* d_idx, const 
 int ya_append_rows(void* d_dst, size_t row_bytes, int n_own, const void* d_src_lo,
     const int* d_count_lo, const void* d_src_hi, const int* d_count_hi, int cap, int* d_n_out,
     void* stream);
+
+/* ---- Slab neighbours over RCCL (multi-GPU, one process per GPU) ------------- */
+
+/* The reference is single-GPU (no communication backend); these entry
+ * points are what its Grid_solver needs to run as z-slabs on the GPUs of one node
+ * (SURVEY.md section 8e): a communicator per process, the exchange of a slab's two ghost
+ * messages with its two neighbours, and the sum of a few floats over all slabs.  RCCL is
+ * loaded on first use (dlopen of librccl.so.1: a single-GPU process never loads it);
+ * ncclSend / ncclRecv inside one group go point-to-point over the direct xGMI links.
+ * All return 0 or a non-zero error code after printing the RCCL / socket error. */
+typedef struct ya_comm ya_comm;
+#define YA_COMM_ID_BYTES 128
+
+/* Rank 0: a fresh unique id (ncclGetUniqueId) to hand to every rank. */
+int ya_comm_unique_id(void* id_out_128_bytes);
+/* Every rank, on its current device: ncclCommInitRank.  world == 1 needs no id and no RCCL. */
+int ya_comm_create(const void* id_128_bytes, int rank, int world, ya_comm** out);
+/* The same with the id passed from rank 0 over TCP: RANK, WORLD_SIZE, MASTER_ADDR and
+ * MASTER_PORT from the environment (the variables torch.distributed.run sets); rank 0 listens
+ * on MASTER_PORT + port_offset.  For model programs without any other launcher support. */
+int ya_comm_create_from_env(int port_offset, ya_comm** out);
+int ya_comm_destroy(ya_comm* comm);
+int ya_comm_rank(const ya_comm* comm);
+int ya_comm_world(const ya_comm* comm);
+/* Slab rank r sends `bytes` bytes of d_send_lo to rank r - 1 and of d_send_hi to rank r + 1 and
+ * receives as many into d_recv_lo / d_recv_hi from them, all in one RCCL group on `stream`
+ * (the first and last rank have one neighbour; their other buffers may be NULL). */
+int ya_comm_exchange(ya_comm* comm, const void* d_send_lo, void* d_recv_lo, const void* d_send_hi,
+    void* d_recv_hi, size_t bytes, void* stream);
+/* In-place sum of `count` floats over all ranks (ncclAllReduce) on `stream`. */
+int ya_comm_allreduce_sum(ya_comm* comm, float* d_buf, int count, void* stream);
+/* The same on host memory through the devices (a bounce buffer): for the few control values a
+ * program needs once (timings, totals); blocking. */
+int ya_comm_allreduce_host(ya_comm* comm, double* values, int count, int take_max);
 
 #pragma GCC visibility pop
 #ifdef __cplusplus

@@ -88,7 +88,7 @@ int ya_sim_set_links(ya_sim* sim, const int* ab, int n_links, float strength);
  * New relative to the reference (single-GPU).  A rank owns the cells with
  * z in [z_lo, z_hi); local arrays hold own cells [0, n_own) then ghosts.  All
  * buffers are device memory (host memory on the oracle) of ya_slab_*_bytes(cap)
- * bytes: a 16-byte header {int count} and `cap` rows per field.  One stage is
+ * bytes: a 16-byte header {int count} and `cap` rows per field (X, old_v, global id).  One stage is
  *   pack_halo(dir 0 -> lower neighbour, 1 -> upper) ; exchange ; unpack_halo ;
  *   stage_rhs ; stage_sum -> {sum[n_floats], n_own & 4095, n_own >> 12} (n_floats + 2 floats:
  *   the count in two pieces that stay exact under a float all-reduce) ; all-reduce ; stage_update
@@ -106,6 +106,23 @@ int ya_slab_stage_update(ya_sim* sim, int stage, float dt, const float* d_total_
 int ya_slab_migrate_pack(ya_sim* sim, void* d_buf_lo, void* d_buf_hi, int cap_cells);
 int ya_slab_migrate_unpack(ya_sim* sim, const void* d_buf_lo, const void* d_buf_hi, int cap_cells);
 int ya_slab_n_own(ya_sim* sim);
+
+/* The same step sequenced in C++ for the one-process-per-rank case: ya_slab_setup allocates
+ * this rank's message buffers (rank r of `world` slabs has neighbours r - 1 and r + 1), a
+ * transport says how they travel, ya_slab_step does one take_step of the decomposed system
+ * (both Heun stages and, if `migrate`, the hand-over of cells that left the slab).
+ * Transports: ya_slab_use_rccl(sim, ya_comm*) -- RCCL send/recv and all-reduce on the device
+ * buffers (include/yalla_hip.h, device build only) -- or two callbacks (tests: gloo, or
+ * messages staged through the host).  exchange: `kind` 0 = ghost layer, 1 = migration;
+ * `bytes` from every present send buffer to that neighbour, as many into the recv buffers;
+ * allreduce: in-place sum of `count` floats over all ranks.  Both return 0 on success. */
+typedef int (*ya_slab_exchange_fn)(void* ctx, int kind, const void* send_lo, void* recv_lo,
+    const void* send_hi, void* recv_hi, long bytes);
+typedef int (*ya_slab_allreduce_fn)(void* ctx, float* buf, int count);
+int ya_slab_setup(ya_sim* sim, int rank, int world, int halo_cap_cells, int migrate_cap_cells);
+int ya_slab_set_transport(ya_sim* sim, ya_slab_exchange_fn exchange, ya_slab_allreduce_fn allreduce, void* ctx);
+int ya_slab_use_rccl(ya_sim* sim, void* comm);
+int ya_slab_step(ya_sim* sim, float dt, int migrate);
 int ya_slab_get_own(ya_sim* sim, float* X_host, int* global_ids_host);
 
 /* Device only (test hook): number of binary32 bit patterns in [first, last] for

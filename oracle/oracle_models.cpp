@@ -25,6 +25,7 @@ void ya_harness_random_sphere(float dist_to_nb, C& cells, unsigned seed)
 // and ya_gather_rows.
 namespace harness_ops {
 inline void* alloc(size_t bytes) { return calloc(1, bytes ? bytes : 4); }
+inline void zero(void* p, size_t bytes) { memset(p, 0, bytes); }
 inline void release(void* p) { free(p); }
 inline size_t select_workspace_bytes(int) { return 4; }
 inline void select_z(const void* X, size_t stride, int n, float z_min, float z_max, int* idx,

@@ -434,6 +434,8 @@ public:
         memcpy(nhood, h, sizeof(h));
     }
     Grid grid;  // public in the oracle so tests can read the four arrays
+    // z-slab decomposition (not in the reference): local index -> global id for the functors
+    const int* d_global_id = nullptr;
 
 protected:
     int nhood[27];
@@ -461,8 +463,10 @@ protected:
                     Pt r = Xi - d_X[pk];
                     float dist = ya_dist3(r.x, r.y, r.z);
                     if (dist >= cube_size) continue;  // :450
-                    F += pw_int(Xi, r, dist, pi, pk);
-                    float friction = pw_friction(Xi, r, dist, pi, pk);
+                    const int gi = d_global_id ? d_global_id[pi] : pi;
+                    const int gk = d_global_id ? d_global_id[pk] : pk;
+                    F += pw_int(Xi, r, dist, gi, gk);
+                    float friction = pw_friction(Xi, r, dist, gi, gk);
                     sum_friction += friction;
                     sum_v += friction * d_old_v[pk];
                 }

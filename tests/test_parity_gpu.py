@@ -199,6 +199,47 @@ def test_links_parity(oracle, device):
     assert_close_positions(Xo, Xd)
 
 
+def test_links_segmented_sum_matches_atomics_and_oracle(oracle, device):
+    """link_forces' atomics-free path (pairs sorted by cell, one sum per cell) against the
+    one-thread-per-link atomics kernel and the oracle: random links, inert links (a == b), a
+    hub cell with more links than the 256-entry segment cut, unused slots beyond *d_n."""
+    n = 3000
+    rng = np.random.default_rng(5)
+    pairs = rng.integers(0, n, size=(5000, 2))
+    pairs[::50, 1] = pairs[::50, 0]            # inert links
+    pairs[1000:1700, 0] = 17                   # a hub
+    res = {}
+    try:
+        for name, lib, seg_min in (("oracle", oracle, None), ("atomics", device, 1 << 30), ("segmented", device, 1)):
+            with Solution("springs_links_grid", n, 50, 1.0, lib=lib) as s:
+                if lib is oracle:
+                    s.set_reduce_order(1)
+                else:
+                    s.set_param("links_segmented_min", seg_min)
+                s.random_sphere(0.5, 42)
+                s.set_links(pairs, 0.2)
+                s.take_step(0.01, 3)
+                res[name] = s.positions()
+    finally:
+        with Solution("springs_links_grid", 8, 50, 1.0, lib=device) as s:
+            s.set_param("links_segmented_min", 1000000)
+    assert_close_positions(res["oracle"], res["atomics"])
+    assert_close_positions(res["oracle"], res["segmented"])
+    # without a hub every cell's sum has a fixed order: the run repeats bit for bit
+    # (the atomics' order, and so their rounding, need not)
+    plain = rng.integers(0, n, size=(5000, 2))
+    runs = []
+    for _ in range(2):
+        with Solution("springs_links_grid", n, 50, 1.0, lib=device) as s:
+            s.set_param("links_segmented_min", 1)
+            s.random_sphere(0.5, 42)
+            s.set_links(plain, 0.2)
+            s.take_step(0.01, 3)
+            runs.append(s.positions())
+            s.set_param("links_segmented_min", 1000000)
+    assert np.array_equal(runs[0].view(np.uint32), runs[1].view(np.uint32))
+
+
 def test_dynamic_n(oracle, device):
     """h_n < n_max: only the first n points take part (solvers.cuh:229)."""
     out = []

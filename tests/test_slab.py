@@ -15,20 +15,25 @@ from yalla_amd.solution import Solution
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def reference_run(lib, n, gs, dist, seed, dt, steps, tree=False):
-    with Solution("springs_grid", n, gs, 1.0, lib=lib) as s:
+def reference_run(lib, n, gs, dist, seed, dt, steps, tree=False, model="springs_grid"):
+    with Solution(model, n, gs, 1.0, lib=lib) as s:
         if lib.ya_models_is_device() == 0:
             s.set_reduce_order(1 if tree else 0)
         s.random_sphere(dist, seed)
+        if model.startswith("sorting"):
+            s.set_param("n_cells", n)
         X0 = s.h_X[:n].copy()
         s.take_step(dt, steps)
         return X0, s.positions()
 
 
-def slab_run(lib, X0, world, gs, dt, steps, device="cpu", migrate_every=1):
+def slab_run(lib, X0, world, gs, dt, steps, device="cpu", migrate_every=1, model="springs_grid"):
     bounds = slab_mod.slab_bounds(X0[:, 2], world)
-    slabs = [slab_mod.Slab("springs_grid", X0, r, world, bounds, gs, lib=lib, device=device)
+    slabs = [slab_mod.Slab(model, X0, r, world, bounds, gs, lib=lib, device=device)
              for r in range(world)]
+    if model.startswith("sorting"):
+        for s in slabs:
+            s.sim.set_param("n_cells", len(X0))  # types split at the GLOBAL id n / 2 (sorting.cu:24)
     comm = slab_mod.LocalComm()
     moved = 0
     owners0 = [set(s.own_cells()[0].tolist()) for s in slabs]
@@ -47,9 +52,9 @@ def slab_run(lib, X0, world, gs, dt, steps, device="cpu", migrate_every=1):
     return X, moved
 
 
-def check(lib, n, world, steps, dt, device="cpu", migrate_every=1):
-    X0, Xref = reference_run(lib, n, 50, 0.5, 3, dt, steps)
-    X, moved = slab_run(lib, X0, world, 50, dt, steps, device, migrate_every)
+def check(lib, n, world, steps, dt, device="cpu", migrate_every=1, model="springs_grid"):
+    X0, Xref = reference_run(lib, n, 50, 0.5, 3, dt, steps, model=model)
+    X, moved = slab_run(lib, X0, world, 50, dt, steps, device, migrate_every, model=model)
     scale = np.abs(Xref).max()
     assert np.abs(X - Xref).max() <= 1e-5 * scale
     return moved
@@ -78,39 +83,99 @@ def test_slabs_thinner_than_the_ghost_layer_are_refused(oracle):
         slab_mod.Slab("springs_grid", X0, 2, 6, bounds, 50, lib=oracle)
 
 
-def test_two_gloo_ranks_match_undivided_system(oracle, tmp_path):
-    """DistComm over gloo, world_size 2, one process per rank (oracle backend)."""
-    out = tmp_path / "slab_gloo.npz"
+def test_id_indexed_functor_in_slabs_oracle(oracle):
+    """examples/sorting.cu's functor asks `i < n / 2`: in a slab it must be given the cells'
+    GLOBAL ids (ghost rows carry them; with local ids every third pair would get the wrong
+    adhesion strength, a factor 3 to 9).  Two and three slabs evolve like the undivided system
+    (small dt: the dense start is violent and amplifies the reordered sums otherwise)."""
+    for world in (2, 3):
+        moved = check(oracle, 3000, world, 6, 0.002, model="sorting_grid")
+        assert moved >= 0
+
+
+def run_ranks(tmp_path, name, port, *worker_args):
+    out = tmp_path / name
     env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.path.join(ROOT, "tests"))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-           "--master-addr", "127.0.0.1", "--master-port", "29611",
-           os.path.join(ROOT, "tests", "slab_worker.py"), str(out)]
-    proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "tests", "slab_worker.py"), str(out), *worker_args]
+    proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-2000:]
-    got = np.load(out)
+    return np.load(out)
+
+
+@pytest.mark.parametrize("sequencing", ["native", "python"])
+def test_two_gloo_ranks_match_undivided_system(oracle, tmp_path, sequencing):
+    """One process per rank over gloo, world_size 2 (oracle backend): the step sequenced in
+    C++ (ya_slab_step, gloo behind the transport callbacks) and by yalla_amd/slab.py."""
+    got = run_ranks(tmp_path, "slab_gloo.npz", 29611 if sequencing == "native" else 29613,
+                    "oracle", sequencing)
     X0, Xref = reference_run(oracle, 3000, 50, 0.5, 3, 0.003, 6)
     assert np.array_equal(got["X0"], X0)
     scale = np.abs(Xref).max()
     assert np.abs(got["X"] - Xref).max() <= 1e-5 * scale
 
 
+def test_two_gloo_ranks_id_indexed_functor(oracle, tmp_path):
+    """sorting_grid (functor indexed by global id) through the C++-sequenced step, 2 ranks."""
+    got = run_ranks(tmp_path, "slab_gloo_sorting.npz", 29615, "oracle", "native", "sorting_grid")
+    X0, Xref = reference_run(oracle, 3000, 50, 0.5, 3, 0.002, 6, model="sorting_grid")
+    assert np.array_equal(got["X0"], X0)
+    scale = np.abs(Xref).max()
+    assert np.abs(got["X"] - Xref).max() <= 1e-5 * scale
+
+
 @pytest.mark.gpu
-def test_two_ranks_sharing_one_gpu_match_undivided_system(device, tmp_path):
-    """The one-process-per-rank path on the device: DistComm, torch device buffers handed to
-    the engine, world_size 2.  RCCL refuses two ranks on one GPU, so the transport is gloo
-    with the messages staged through host memory; everything else is what bench.py runs."""
-    out = tmp_path / "slab_gloo_device.npz"
-    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.path.join(ROOT, "tests"))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-           "--master-addr", "127.0.0.1", "--master-port", "29612",
-           os.path.join(ROOT, "tests", "slab_worker.py"), str(out), "device"]
-    proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
-    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-2000:]
-    got = np.load(out)
+@pytest.mark.parametrize("sequencing", ["native", "python"])
+def test_two_ranks_sharing_one_gpu_match_undivided_system(device, tmp_path, sequencing):
+    """The one-process-per-rank path on the device, world_size 2.  RCCL refuses two ranks on
+    one GPU, so the transport is gloo with the messages staged through host memory; the
+    sequencing (C++ ya_slab_step or slab.py) and all device work are what bench.py runs."""
+    got = run_ranks(tmp_path, "slab_gloo_device.npz", 29612 if sequencing == "native" else 29614,
+                    "device", sequencing)
     X0, Xref = reference_run(device, 40000, 50, 0.5, 3, 0.003, 6)
     assert np.array_equal(got["X0"], X0)
     scale = np.abs(Xref).max()
     assert np.abs(got["X"] - Xref).max() <= 1e-5 * scale
+
+
+@pytest.mark.gpu
+def test_id_indexed_functor_in_slabs_device(device):
+    """sorting_grid in 2 and 4 slabs on the device against the undivided system."""
+    for world in (2, 4):
+        moved = check(device, 40000, world, 6, 0.002, device="hip", model="sorting_grid")
+        assert moved >= 0
+
+
+@pytest.mark.gpu
+def test_rccl_communicator_single_rank(device):
+    """ya_comm_* with world_size 1 on the GPU box (RCCL needs one GPU per rank): creation from
+    the environment, the host all-reduce, and ya_slab_step driven through ya_slab_use_rccl."""
+    env_keep = {k: os.environ.get(k) for k in ("RANK", "WORLD_SIZE")}
+    os.environ["RANK"], os.environ["WORLD_SIZE"] = "0", "1"
+    try:
+        comm = slab_mod.NativeComm()
+        assert (comm.rank, comm.world) == (0, 1)
+        assert comm.allreduce_host([1.5, 2.0]) == [1.5, 2.0]
+        X0, Xref = reference_run(device, 20000, 50, 0.5, 3, 0.003, 4)
+        bounds = slab_mod.slab_bounds(X0[:, 2], 1)
+        sl = slab_mod.Slab("springs_grid", X0, 0, 1, bounds, 50, lib=device, device="hip",
+                           python_buffers=False)
+        sl.setup_native_step(comm=comm)
+        for _ in range(4):
+            sl.step_native(0.003)
+        gid, X = sl.own_cells()
+        full = np.zeros_like(X0)
+        full[gid] = X
+        assert np.abs(full - Xref).max() <= 1e-5 * np.abs(Xref).max()
+        sl.close()
+        comm.close()
+    finally:
+        for k, v in env_keep.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 @pytest.mark.gpu

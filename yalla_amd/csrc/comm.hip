@@ -1,0 +1,297 @@
+// RCCL slab-neighbour communication behind include/yalla_hip.h (ya_comm_*).
+//
+// One process per GPU.  RCCL is bound at run time (dlopen) so that libyalla_hip.so has
+// no link-time dependency on it: single-GPU programs never load it, and a process that
+// already carries an RCCL (PyTorch's) shares that copy through the common soname.
+#include <hip/hip_runtime.h>
+
+#include <arpa/inet.h>
+#include <dlfcn.h>
+#include <errno.h>
+#include <netdb.h>
+#include <netinet/in.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/socket.h>
+#include <unistd.h>
+
+#include "yalla_hip.h"
+
+namespace {
+
+// the part of rccl.h this file needs (ABI-stable NCCL 2 declarations)
+typedef struct ncclComm* ncclComm_t;
+typedef struct {
+    char internal[YA_COMM_ID_BYTES];
+} ncclUniqueId;
+typedef int ncclResult_t;
+enum { NCCL_INT8 = 0, NCCL_FLOAT32 = 7, NCCL_FLOAT64 = 8 };
+enum { NCCL_SUM = 0, NCCL_MAX = 2 };
+
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+Rccl* rccl()
+{
+    static Rccl r;
+    static bool tried = false;
+    if (tried) return r.lib ? &r : nullptr;
+    tried = true;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* name : names) {
+        r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (r.lib) break;
+    }
+    if (!r.lib) {
+        fprintf(stderr, "yalla-hip: cannot load RCCL (librccl.so.1): %s\n", dlerror());
+        return nullptr;
+    }
+#define YA_SYM(field, name)                                                      \
+    *(void**)(&r.field) = dlsym(r.lib, name);                                    \
+    if (!r.field) {                                                              \
+        fprintf(stderr, "yalla-hip: RCCL lacks %s\n", name);                     \
+        r.lib = nullptr;                                                         \
+        return nullptr;                                                          \
+    }
+    YA_SYM(GetUniqueId, "ncclGetUniqueId")
+    YA_SYM(CommInitRank, "ncclCommInitRank")
+    YA_SYM(CommDestroy, "ncclCommDestroy")
+    YA_SYM(Send, "ncclSend")
+    YA_SYM(Recv, "ncclRecv")
+    YA_SYM(AllReduce, "ncclAllReduce")
+    YA_SYM(GroupStart, "ncclGroupStart")
+    YA_SYM(GroupEnd, "ncclGroupEnd")
+    YA_SYM(GetErrorString, "ncclGetErrorString")
+#undef YA_SYM
+    return &r;
+}
+
+int rccl_error(const char* what, ncclResult_t code)
+{
+    Rccl* r = rccl();
+    fprintf(stderr, "yalla-hip: %s failed: %s\n", what, r ? r->GetErrorString(code) : "RCCL not loaded");
+    return 1000 + (int)code;
+}
+
+#define YA_RCCL(call, what)                       \
+    do {                                          \
+        const ncclResult_t rc_ = (call);          \
+        if (rc_ != 0) return rccl_error(what, rc_); \
+    } while (0)
+
+int send_all(int fd, const void* data, size_t bytes)
+{
+    const char* p = (const char*)data;
+    while (bytes > 0) {
+        const ssize_t k = send(fd, p, bytes, 0);
+        if (k <= 0) return -1;
+        p += k;
+        bytes -= (size_t)k;
+    }
+    return 0;
+}
+
+int recv_all(int fd, void* data, size_t bytes)
+{
+    char* p = (char*)data;
+    while (bytes > 0) {
+        const ssize_t k = recv(fd, p, bytes, 0);
+        if (k <= 0) return -1;
+        p += k;
+        bytes -= (size_t)k;
+    }
+    return 0;
+}
+
+}  // namespace
+
+struct ya_comm {
+    int rank = 0, world = 1;
+    ncclComm_t comm = nullptr;
+    double* d_bounce = nullptr;  // 64 doubles for ya_comm_allreduce_host
+};
+
+extern "C" {
+
+int ya_comm_unique_id(void* id_out)
+{
+    Rccl* r = rccl();
+    if (!r || !id_out) return 999;
+    ncclUniqueId id;
+    YA_RCCL(r->GetUniqueId(&id), "ncclGetUniqueId");
+    memcpy(id_out, &id, sizeof(id));
+    return 0;
+}
+
+int ya_comm_create(const void* id_bytes, int rank, int world, ya_comm** out)
+{
+    if (!out || world < 1 || rank < 0 || rank >= world) return (int)hipErrorInvalidValue;
+    ya_comm* c = new ya_comm;
+    c->rank = rank;
+    c->world = world;
+    if (world > 1) {
+        Rccl* r = rccl();
+        if (!r || !id_bytes) {
+            delete c;
+            return 999;
+        }
+        ncclUniqueId id;
+        memcpy(&id, id_bytes, sizeof(id));
+        const ncclResult_t rc = r->CommInitRank(&c->comm, world, id, rank);
+        if (rc != 0) {
+            delete c;
+            return rccl_error("ncclCommInitRank", rc);
+        }
+        if (hipMalloc(&c->d_bounce, 64 * sizeof(double)) != hipSuccess) {
+            (void)r->CommDestroy(c->comm);
+            delete c;
+            return (int)hipErrorOutOfMemory;
+        }
+    }
+    *out = c;
+    return 0;
+}
+
+int ya_comm_create_from_env(int port_offset, ya_comm** out)
+{
+    const char* s_rank = getenv("RANK");
+    const char* s_world = getenv("WORLD_SIZE");
+    const int rank = s_rank ? atoi(s_rank) : 0;
+    const int world = s_world ? atoi(s_world) : 1;
+    if (world <= 1) return ya_comm_create(nullptr, 0, 1, out);
+    const char* addr = getenv("MASTER_ADDR") ? getenv("MASTER_ADDR") : "127.0.0.1";
+    const int port = (getenv("MASTER_PORT") ? atoi(getenv("MASTER_PORT")) : 29500) + port_offset;
+    char id[YA_COMM_ID_BYTES];
+    if (rank == 0) {
+        const int rc = ya_comm_unique_id(id);
+        if (rc) return rc;
+        const int srv = socket(AF_INET, SOCK_STREAM, 0);
+        int yes = 1;
+        setsockopt(srv, SOL_SOCKET, SO_REUSEADDR, &yes, sizeof(yes));
+        sockaddr_in sa{};
+        sa.sin_family = AF_INET;
+        sa.sin_addr.s_addr = htonl(INADDR_ANY);
+        sa.sin_port = htons((unsigned short)port);
+        if (srv < 0 || bind(srv, (sockaddr*)&sa, sizeof(sa)) != 0 || listen(srv, world) != 0) {
+            fprintf(stderr, "yalla-hip: rank 0 cannot listen on port %d: %s\n", port, strerror(errno));
+            if (srv >= 0) close(srv);
+            return 998;
+        }
+        for (int k = 1; k < world; k++) {
+            const int fd = accept(srv, nullptr, nullptr);
+            if (fd < 0 || send_all(fd, id, sizeof(id)) != 0) {
+                fprintf(stderr, "yalla-hip: rank 0 could not hand the id to a rank: %s\n", strerror(errno));
+                if (fd >= 0) close(fd);
+                close(srv);
+                return 998;
+            }
+            close(fd);
+        }
+        close(srv);
+    } else {
+        addrinfo hints{}, *res = nullptr;
+        hints.ai_family = AF_INET;
+        hints.ai_socktype = SOCK_STREAM;
+        char port_s[16];
+        snprintf(port_s, sizeof(port_s), "%d", port);
+        if (getaddrinfo(addr, port_s, &hints, &res) != 0 || !res) {
+            fprintf(stderr, "yalla-hip: cannot resolve MASTER_ADDR %s\n", addr);
+            return 998;
+        }
+        int fd = -1;
+        for (int attempt = 0; attempt < 6000; attempt++) {  // rank 0 may not listen yet (first import of a big runtime): up to ten minutes
+            fd = socket(AF_INET, SOCK_STREAM, 0);
+            if (fd >= 0 && connect(fd, res->ai_addr, res->ai_addrlen) == 0) break;
+            if (fd >= 0) close(fd);
+            fd = -1;
+            usleep(100000);
+        }
+        freeaddrinfo(res);
+        if (fd < 0 || recv_all(fd, id, sizeof(id)) != 0) {
+            fprintf(stderr, "yalla-hip: rank %d got no id from %s:%d\n", rank, addr, port);
+            if (fd >= 0) close(fd);
+            return 998;
+        }
+        close(fd);
+    }
+    return ya_comm_create(id, rank, world, out);
+}
+
+int ya_comm_destroy(ya_comm* c)
+{
+    if (!c) return 0;
+    if (c->comm) {
+        Rccl* r = rccl();
+        if (r) (void)r->CommDestroy(c->comm);
+    }
+    if (c->d_bounce) (void)hipFree(c->d_bounce);
+    delete c;
+    return 0;
+}
+
+int ya_comm_rank(const ya_comm* c) { return c ? c->rank : 0; }
+int ya_comm_world(const ya_comm* c) { return c ? c->world : 1; }
+
+int ya_comm_exchange(ya_comm* c, const void* d_send_lo, void* d_recv_lo, const void* d_send_hi,
+    void* d_recv_hi, size_t bytes, void* stream)
+{
+    if (!c) return (int)hipErrorInvalidValue;
+    if (c->world == 1 || bytes == 0) return 0;
+    Rccl* r = rccl();
+    if (!r) return 999;
+    hipStream_t st = (hipStream_t)stream;
+    const bool lo = c->rank > 0, hi = c->rank + 1 < c->world;
+    if ((lo && (!d_send_lo || !d_recv_lo)) || (hi && (!d_send_hi || !d_recv_hi)))
+        return (int)hipErrorInvalidValue;
+    YA_RCCL(r->GroupStart(), "ncclGroupStart");
+    if (lo) {
+        YA_RCCL(r->Send(d_send_lo, bytes, NCCL_INT8, c->rank - 1, c->comm, st), "ncclSend (lower slab)");
+        YA_RCCL(r->Recv(d_recv_lo, bytes, NCCL_INT8, c->rank - 1, c->comm, st), "ncclRecv (lower slab)");
+    }
+    if (hi) {
+        YA_RCCL(r->Send(d_send_hi, bytes, NCCL_INT8, c->rank + 1, c->comm, st), "ncclSend (upper slab)");
+        YA_RCCL(r->Recv(d_recv_hi, bytes, NCCL_INT8, c->rank + 1, c->comm, st), "ncclRecv (upper slab)");
+    }
+    YA_RCCL(r->GroupEnd(), "ncclGroupEnd");
+    return 0;
+}
+
+int ya_comm_allreduce_sum(ya_comm* c, float* d_buf, int count, void* stream)
+{
+    if (!c || !d_buf || count < 0) return (int)hipErrorInvalidValue;
+    if (c->world == 1 || count == 0) return 0;
+    Rccl* r = rccl();
+    if (!r) return 999;
+    YA_RCCL(r->AllReduce(d_buf, d_buf, (size_t)count, NCCL_FLOAT32, NCCL_SUM, c->comm, (hipStream_t)stream),
+        "ncclAllReduce");
+    return 0;
+}
+
+int ya_comm_allreduce_host(ya_comm* c, double* values, int count, int take_max)
+{
+    if (!c || !values || count < 0 || count > 64) return (int)hipErrorInvalidValue;
+    if (c->world == 1 || count == 0) return 0;
+    Rccl* r = rccl();
+    if (!r) return 999;
+    if (hipMemcpy(c->d_bounce, values, (size_t)count * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
+        return (int)hipGetLastError();
+    YA_RCCL(r->AllReduce(c->d_bounce, c->d_bounce, (size_t)count, NCCL_FLOAT64, take_max ? NCCL_MAX : NCCL_SUM,
+                c->comm, nullptr),
+        "ncclAllReduce (host values)");
+    if (hipMemcpy(values, c->d_bounce, (size_t)count * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+        return (int)hipGetLastError();
+    return 0;
+}
+
+}  // extern "C"

@@ -33,6 +33,7 @@ inline void* alloc(size_t bytes)
     YA_CHECK(ya_malloc(&p, bytes));
     return p;
 }
+inline void zero(void* p, size_t bytes) { YA_CHECK(ya_memset_async(p, 0, bytes, nullptr)); }
 inline void release(void* p) { ya_free(p); }
 inline size_t select_workspace_bytes(int n_max) { return ya_select_workspace_bytes(n_max); }
 inline void select_z(const void* X, size_t stride, int n, float z_min, float z_max, int* idx,

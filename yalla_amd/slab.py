@@ -107,6 +107,115 @@ class _Buffer:
             self.tensor.copy_(other.tensor)
 
 
+# callback signatures of include/yalla_models.h (ya_slab_exchange_fn, ya_slab_allreduce_fn)
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int)
+
+
+class NativeComm:
+    """RCCL communicator of libyalla_hip.so (ya_comm_*): one per process, on the current
+    device.  The unique id comes from rank 0 over TCP (RANK / WORLD_SIZE / MASTER_ADDR /
+    MASTER_PORT, as torch.distributed.run sets them): no torch.distributed needed."""
+
+    def __init__(self, port_offset=1):
+        lib = _core_lib()
+        lib.ya_comm_create_from_env.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        lib.ya_comm_destroy.argtypes = [C.c_void_p]
+        lib.ya_comm_rank.argtypes = [C.c_void_p]
+        lib.ya_comm_world.argtypes = [C.c_void_p]
+        lib.ya_comm_allreduce_host.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int]
+        self._lib = lib
+        handle = C.c_void_p()
+        code = lib.ya_comm_create_from_env(int(port_offset), C.byref(handle))
+        if code != 0:
+            raise YallaError(f"ya_comm_create_from_env failed ({code})")
+        self.handle = handle
+        self.rank, self.world = lib.ya_comm_rank(handle), lib.ya_comm_world(handle)
+
+    def allreduce_host(self, values, take_max=False):
+        """Sum (or max) of a few host doubles over all ranks; blocking."""
+        arr = (C.c_double * len(values))(*values)
+        code = self._lib.ya_comm_allreduce_host(self.handle, arr, len(values), 1 if take_max else 0)
+        if code != 0:
+            raise YallaError(f"ya_comm_allreduce_host failed ({code})")
+        return list(arr)
+
+    def barrier(self):
+        self.allreduce_host([0.0])
+
+    def close(self):
+        if self.handle:
+            self._lib.ya_comm_destroy(self.handle)
+            self.handle = None
+
+
+class CallbackTransport:
+    """torch.distributed (gloo) behind the C++-sequenced step (ya_slab_step): the engine calls
+    back with raw buffer pointers; host memory (oracle) is wrapped in place, device memory is
+    staged through the host (tests: RCCL refuses two ranks on one GPU)."""
+
+    def __init__(self, device_memory):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.device_memory = device_memory
+        self.exchange_fn = EXCHANGE_FN(self._exchange)
+        self.allreduce_fn = ALLREDUCE_FN(self._allreduce)
+
+    def _host_view(self, ptr, nbytes):
+        return np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(ptr))
+
+    def _read(self, ptr, nbytes):
+        if not self.device_memory:
+            return self._host_view(ptr, nbytes)
+        out = np.empty(nbytes, np.uint8)
+        assert _core_lib().ya_memcpy_d2h(out.ctypes.data, C.c_void_p(ptr), nbytes) == 0
+        return out
+
+    def _write(self, ptr, data):
+        if self.device_memory:
+            assert _core_lib().ya_memcpy_h2d(C.c_void_p(ptr), data.ctypes.data, data.nbytes) == 0
+
+    def _exchange(self, ctx, kind, send_lo, recv_lo, send_hi, recv_hi, nbytes):
+        try:
+            torch, dist = self.torch, self.dist
+            ops, landed = [], []
+            for send, recv, peer in ((send_lo, recv_lo, self.rank - 1), (send_hi, recv_hi, self.rank + 1)):
+                if not send or peer < 0 or peer >= self.world:
+                    continue
+                out = torch.from_numpy(np.ascontiguousarray(self._read(send, nbytes)))
+                into = self._host_view(recv, nbytes) if not self.device_memory else np.empty(nbytes, np.uint8)
+                landed.append((recv, into))
+                ops.append(dist.P2POp(dist.isend, out, peer))
+                ops.append(dist.P2POp(dist.irecv, torch.from_numpy(into), peer))
+            if ops:
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+            for recv, into in landed:
+                self._write(recv, into)
+            return 0
+        except Exception as err:  # must not propagate into C
+            import sys
+            print("slab exchange callback failed:", err, file=sys.stderr)
+            return 1
+
+    def _allreduce(self, ctx, buf, count):
+        try:
+            data = self._read(buf, 4 * count).view(np.float32).copy()
+            t = self.torch.from_numpy(data)
+            self.dist.all_reduce(t)
+            if self.device_memory:
+                self._write(buf, data.view(np.uint8))
+            else:
+                self._host_view(buf, 4 * count).view(np.float32)[:] = data
+            return 0
+        except Exception as err:
+            import sys
+            print("slab all-reduce callback failed:", err, file=sys.stderr)
+            return 1
+
+
 def slab_bounds(z, world):
     """Cut planes that give every rank the same number of cells: rank r owns
     z in [bounds[r], bounds[r + 1]); the outer faces are at -inf / +inf."""
@@ -119,7 +228,8 @@ class Slab:
     """One rank's share of the system."""
 
     def __init__(self, model, X_all, rank, world, bounds, grid_size, cube_size=1.0,
-                 halo_margin=0.25, lib=None, device="cpu", slack=1.15):
+                 halo_margin=0.25, lib=None, device="cpu", slack=1.15, python_buffers=True,
+                 global_ids=True):
         X_all = np.asarray(X_all, dtype=np.float32)
         self.rank, self.world = rank, world
         self.z_lo, self.z_hi = float(bounds[rank]), float(bounds[rank + 1])
@@ -148,15 +258,20 @@ class Slab:
         self._lib, self._h = lib, self.sim._h
         _check(lib.ya_slab_init(self._h, self.z_lo, self.z_hi, halo,
                                 own.ctypes.data_as(C.POINTER(C.c_int))), "ya_slab_init")
+        if not global_ids:  # functors that only compare i with j: spare the id gather per pair
+            self.sim.set_param("slab_global_ids", 0)
         hb = lib.ya_slab_halo_bytes(self._h, self.halo_cap)
         mb = lib.ya_slab_migrate_bytes(self._h, self.mig_cap)
         has = (rank > 0, rank < world - 1)  # neighbour below / above
+        self.n_local = len(own)
+        self._transport = None
+        if not python_buffers:  # the step is sequenced in C++ (setup_native_step / step_native)
+            return
         self.send = {("halo", d): _Buffer(hb, device) if has[d] else None for d in (0, 1)}
         self.recv = {("halo", d): _Buffer(hb, device) if has[d] else None for d in (0, 1)}
         self.send.update({("mig", d): _Buffer(mb, device) if has[d] else None for d in (0, 1)})
         self.recv.update({("mig", d): _Buffer(mb, device) if has[d] else None for d in (0, 1)})
         self.sum = _Buffer(4 * (self.n_floats + 2), device)  # sum of dX, cell count in two exact pieces
-        self.n_local = len(own)
 
     @staticmethod
     def _p(buf):
@@ -164,6 +279,26 @@ class Slab:
 
     def n_own(self):
         return self._lib.ya_slab_n_own(self._h)
+
+    # --- the step sequenced in C++ (one process per rank): ya_slab_setup / ya_slab_step ---
+    def setup_native_step(self, comm=None, transport=None):
+        """`comm`: a NativeComm (RCCL on the device buffers); `transport`: a CallbackTransport."""
+        _check(self._lib.ya_slab_setup(self._h, self.rank, self.world, self.halo_cap, self.mig_cap),
+               "ya_slab_setup")
+        if comm is not None:
+            _check(self._lib.ya_slab_use_rccl(self._h, comm.handle), "ya_slab_use_rccl")
+        elif transport is not None:
+            self._transport = transport  # keeps the ctypes callbacks alive
+            _check(self._lib.ya_slab_set_transport(
+                self._h, C.cast(transport.exchange_fn, C.c_void_p), C.cast(transport.allreduce_fn, C.c_void_p),
+                None), "ya_slab_set_transport")
+
+    def step_native(self, dt, migrate=True):
+        code = self._lib.ya_slab_step(self._h, float(dt), 1 if migrate else 0)
+        if code != 0:
+            raise YallaError(f"rank {self.rank}: ya_slab_step failed ({code}): -4 = a ghost layer or the "
+                             "migrating cells outgrew their message, -5 = n_max too small, "
+                             "-7 = no transport, -8 = the transport failed")
 
     def pack_halo(self, stage):
         for d in (0, 1):
