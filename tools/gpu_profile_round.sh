@@ -12,12 +12,13 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o k -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $out/stats_bench.json 2> $out/stats.err
 i=0
 for pass in "FETCH_SIZE" "WRITE_SIZE" \
-  "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
-  "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU" \
-  "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_WAVES GRBM_GUI_ACTIVE" \
+  "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS" \
+  "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_BRANCH SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_SALU SQ_WAIT_INST_LDS" \
+  "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_TRANS_F32 SQ_WAVES GRBM_GUI_ACTIVE" \
   "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum" \
   "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
   i=$((i+1))
   rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $out/pmc$i -o p -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 10 --warmup 2 > $out/pmc$i.json 2> $out/pmc$i.err
 done
+python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py "$out/pmc*/*counter_collection.csv" > $out/pmc_summary.txt
 ls $out

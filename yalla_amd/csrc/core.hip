@@ -213,6 +213,11 @@ __global__ __launch_bounds__(BLOCK) void k_scatter(const int* __restrict__ cube_
 // Rank-count inside the cube's segment: slot of point p = segment start +
 // #(points of the segment with a smaller id).  NW = floats per point (0 = no
 // gather).
+// Cost bound: a cell compares its id with the m cells of its own cube (m loads, m compares),
+// so a cube costs m^2 -- the same order as, and 27 times less than, the 27 m candidate tests
+// the force kernel then runs for each of those cells.  Dense or collapsed populations slow
+// the force evaluation down long before they slow this kernel down; a plain Grid::build
+// used on its own (model kernels that only need the cube lists) pays the m^2 as well.
 template<int NW>
 __global__ __launch_bounds__(BLOCK) void k_order(const int* __restrict__ arrival_pid,
     const int* __restrict__ cube_id_sorted, const int* __restrict__ offs, int n,
