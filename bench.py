@@ -156,7 +156,7 @@ def measured_counters(kernel_key):
             rec = json.load(f)[kernel_key]
     except (OSError, KeyError, ValueError):
         return {}, None
-    out = {k: rec.get(k) for k in ("valu_issue_frac", "lanes_active_frac", "lds_conflict_frac",
+    out = {k: rec.get(k) for k in ("valu_issue_frac", "valu_rate_frac", "lanes_active_frac", "lds_conflict_frac",
                                    "lds_busy_frac", "wait_frac", "valu_insts_per_wave")}
     out["traffic"] = (2 * rec["FETCH_SIZE_KiB"] + rec["WRITE_SIZE_KiB"]) * 1024.0
     head = {"commit": rec.get("head"), "kernel_sha": rec.get("kernel_sha")}
@@ -472,7 +472,8 @@ def main(argv=None):
                 "gather_model_GBs": gather_bytes * value / world / 1e9,
                 "gather_model_bytes_per_cell_update": gather_bytes,
                 # the ceilings that do bind this kernel (PMC passes under profiles/, same command)
-                "valu_issue_frac": counters.get("valu_issue_frac"),
+                "valu_issue_frac": counters.get("valu_issue_frac"),   # at the ideal 2 cycles per wave64 VALU
+                "valu_rate_frac": counters.get("valu_rate_frac"),     # at the chip's measured sustained rate
                 "lanes_active_frac": counters.get("lanes_active_frac"),
                 "lds_conflict_frac": counters.get("lds_conflict_frac"),
                 "lds_busy_frac": counters.get("lds_busy_frac"),
