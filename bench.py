@@ -122,6 +122,8 @@ def parse(argv=None):
     ap.add_argument("--links-per-cell", type=int, default=3,
                     help="springs_links_grid: links from every cell to this many nearest neighbours "
                          "(protrusion-like load for Links::link_forces)")
+    ap.add_argument("--tile-lanes", type=int, default=1,
+                    help="Tile_solver models: Tile_computer::lanes_per_cell (1 = reference semantics, 16 = tile_force_coop)")
     ap.add_argument("--graph", type=int, default=0,
                     help="Heun_solver::graph_steps: 1 = replay the step as a hipGraph, -1 = below 400 k "
                          "cells only, 0 = plain launches (default)")
@@ -329,6 +331,8 @@ def main(argv=None):
                 sim.set_param("graph", args.graph)
         if args.model.startswith("sorting"):
             sim.set_param("n_cells", n_total)
+        if args.model.endswith("_tile") and args.tile_lanes != 1:
+            sim.set_param("tile_lanes", args.tile_lanes)
         n_links = 0
         if args.model == "springs_links_grid" and args.links_per_cell > 0:
             # every cell linked to its k nearest neighbours (as the protrusions of

@@ -316,6 +316,141 @@ __global__ __launch_bounds__(TILE_BLOCK) void tile_force(const int n,
     if (i < n) store_rhs(d_dX, i, has_gen, F, sum_v, sum_friction);
 }
 
+// The same all-pairs force with 16 or 64 lanes per cell (opt-in: Tile_computer::lanes_per_cell).
+// All pairs of 800 cells are only 13 wavefronts for tile_force, each lane walking its 800
+// partners alone: 0.19 ms per launch on a 256-CU chip.  Here a 256-thread workgroup owns 16 or 4
+// cells; for every tile of up to 512 partners each cell's lanes evaluate eight pairs apiece and
+// leave {F, friction, friction * old_v} in LDS, then ONE lane per component runs that
+// component's sum over the tile in ascending j -- every per-cell sum is still accumulated in
+// exactly the reference's order, and results are bit-identical to tile_force.  What changes:
+// the functor is called for one i from several lanes at once, so functors that update per-cell
+// state non-atomically (d_mes_nbs[i] += 1, examples/passive_growth.cu:48-51) must keep the
+// default of one lane per cell.
+
+template<typename Pt, Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction, int COOP_LANES>
+__global__ __launch_bounds__(256) void tile_force_coop(const int n,
+    const Pt* __restrict__ d_X, const float3* __restrict__ d_old_v, Pt* __restrict__ d_dX,
+    const bool has_gen)
+{
+    constexpr int COOP_CELLS = 256 / COOP_LANES;
+    constexpr int NF = N_floats<Pt>::value;
+    constexpr int NC = NF + 4;  // components summed per cell: F (NF), friction, friction * old_v (3)
+    // partners per tile: a multiple of 64 whose terms fill at most 56 KiB of LDS
+    constexpr int TILE = (57344 / (COOP_CELLS * NC * 4)) / 64 * 64 > 512 ? 512 : (57344 / (COOP_CELLS * NC * 4)) / 64 * 64;
+    static_assert(TILE >= 64, "point type too large for tile_force_coop");
+    constexpr int THREADS = COOP_CELLS * COOP_LANES;
+    constexpr int LOADS = (TILE + THREADS - 1) / THREADS;  // partners a thread carries per tile
+    constexpr int SLOTS = (NC + COOP_LANES - 1) / COOP_LANES;
+    __shared__ __attribute__((aligned(16))) float sh_part[COOP_CELLS][NC][TILE];  // one tile's terms, [cell][component][j]
+    __shared__ Pt sh_X[TILE];                        // the tile's partners
+    __shared__ float3 sh_v[TILE];
+    __shared__ float sh_sum[COOP_CELLS][NC];
+
+    const int cell = threadIdx.x / COOP_LANES, lane = threadIdx.x % COOP_LANES;
+    const int i = blockIdx.x * COOP_CELLS + cell;
+    const bool active = i < n;
+    Pt Xi = ya::zero<Pt>();
+    if (active) Xi = d_X[i];
+    float acc[SLOTS];  // this lane's component sums (components lane, lane + COOP_LANES, ...)
+#pragma unroll
+    for (int a = 0; a < SLOTS; a++) acc[a] = 0.f;
+
+    // the next tile's partners travel from global memory while the current tile is worked on
+    Pt x_next[LOADS];
+    float3 v_next[LOADS];
+#pragma unroll
+    for (int k = 0; k < LOADS; k++) {
+        const int j = threadIdx.x + k * THREADS;
+        x_next[k] = ya::zero<Pt>();
+        v_next[k] = float3{0.f, 0.f, 0.f};
+        if (j < TILE && j < n) {
+            x_next[k] = d_X[j];
+            v_next[k] = d_old_v[j];
+        }
+    }
+    for (int tile_start = 0; tile_start < n; tile_start += TILE) {
+        const int n_tile = min(TILE, n - tile_start);
+#pragma unroll
+        for (int k = 0; k < LOADS; k++) {
+            const int t = threadIdx.x + k * THREADS;
+            if (t < TILE) {
+                sh_X[t] = x_next[k];
+                sh_v[t] = v_next[k];
+                const int j_next = tile_start + TILE + t;
+                if (j_next < n) {
+                    x_next[k] = d_X[j_next];
+                    v_next[k] = d_old_v[j_next];
+                }
+            }
+        }
+        __syncthreads();
+        // (a) the tile's pair terms: lane l takes partners l, l + COOP_LANES, ...
+        if (active) {
+#pragma unroll 4
+            for (int jj = lane; jj < n_tile; jj += COOP_LANES) {
+                const int j = tile_start + jj;
+                Pt r = Xi - sh_X[jj];
+                float dist = dist3(r.x, r.y, r.z);
+                const Pt f = pw_int(Xi, r, dist, i, j);
+                const float friction = pw_friction(Xi, r, dist, i, j);
+#pragma unroll
+                for (int c = 0; c < NF; c++) sh_part[cell][c][jj] = field(f, c);
+                sh_part[cell][NF][jj] = friction;
+                const float3 v = sh_v[jj];
+                sh_part[cell][NF + 1][jj] = friction * v.x;
+                sh_part[cell][NF + 2][jj] = friction * v.y;
+                sh_part[cell][NF + 3][jj] = friction * v.z;
+            }
+        }
+        __syncthreads();
+        // (b) one lane per component adds the tile's terms in ascending j
+#pragma unroll
+        for (int a = 0; a < SLOTS; a++) {
+            const int c = lane + COOP_LANES * a;
+            if (c < NC && active) {
+                // sixteen terms per trip: four 16-byte LDS reads in flight, then the adds in order
+                float sum = acc[a];
+                const float4* terms = reinterpret_cast<const float4*>(&sh_part[cell][c][0]);
+                const float4* frictions = reinterpret_cast<const float4*>(&sh_part[cell][NF][0]);
+                const bool conditional = c > NF;  // the old_v term only where the friction is not zero
+                int jj = 0;                        // (solvers.cuh:312-316)
+                for (; jj + 16 <= n_tile; jj += 16) {
+                    float4 p[4], fr[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        p[u] = terms[jj / 4 + u];
+                        fr[u] = conditional ? frictions[jj / 4 + u] : float4{1.f, 1.f, 1.f, 1.f};
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        sum = fr[u].x != 0 ? sum + p[u].x : sum;
+                        sum = fr[u].y != 0 ? sum + p[u].y : sum;
+                        sum = fr[u].z != 0 ? sum + p[u].z : sum;
+                        sum = fr[u].w != 0 ? sum + p[u].w : sum;
+                    }
+                }
+                for (; jj < n_tile; jj++)
+                    if (!conditional || sh_part[cell][NF][jj] != 0) sum += sh_part[cell][c][jj];
+                acc[a] = sum;
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < SLOTS; a++) {
+        const int c = lane + COOP_LANES * a;
+        if (c < NC) sh_sum[cell][c] = acc[a];
+    }
+    __syncthreads();
+    if (active && lane == 0) {
+        Pt F;
+#pragma unroll
+        for (int c = 0; c < NF; c++) field(F, c) = sh_sum[cell][c];
+        store_rhs(d_dX, i, has_gen, F,
+            float3{sh_sum[cell][NF + 1], sh_sum[cell][NF + 2], sh_sum[cell][NF + 3]}, sh_sum[cell][NF]);
+    }
+}
+
 // Row r of the 27-cube stencil in the reference's d_nhood order
 // (solvers.cuh:472-483): rows of three consecutive cube ids centred on
 // 0, -gs, +gs, then the same three shifted by -gs^2, then by +gs^2.
@@ -1511,6 +1646,11 @@ public:
     Tile_computer(int n_max) {}
     ya::Profiler profiler;
     bool use_sorted_pipeline() const { return false; }
+    // 1 (default) = one thread owns a cell for the whole stage, as in the reference; 16 or 64 =
+    // ya::tile_force_coop with that many lanes per cell (bit-identical sums; force launch at 800
+    // cells 196 -> 32 us with 64 lanes, at 3000 cells 631 -> 135 us with 16), for functors that
+    // keep no per-cell state non-atomically.
+    int lanes_per_cell = 1;
 
 protected:
     hipStream_t stream = nullptr;  // every launch of a step goes here (null = the default stream)
@@ -1530,9 +1670,16 @@ protected:
         assert(n_active == n);  // Tile_solver is single-GPU only (all pairs)
         hipEvent_t start, stop;
         profiler.next(&start, &stop);
-        hipExtLaunchKernelGGL((ya::tile_force<Pt, pw_int, pw_friction>),
-            dim3((n + ya::TILE_BLOCK - 1) / ya::TILE_BLOCK), dim3(ya::TILE_BLOCK), 0, nullptr,
-            start, stop, 0, n, d_X, d_old_v, d_dX, has_gen);
+        if (lanes_per_cell >= 64)
+            hipExtLaunchKernelGGL((ya::tile_force_coop<Pt, pw_int, pw_friction, 64>), dim3((n + 3) / 4),
+                dim3(256), 0, stream, start, stop, 0, n, d_X, d_old_v, d_dX, has_gen);
+        else if (lanes_per_cell > 1)
+            hipExtLaunchKernelGGL((ya::tile_force_coop<Pt, pw_int, pw_friction, 16>), dim3((n + 15) / 16),
+                dim3(256), 0, stream, start, stop, 0, n, d_X, d_old_v, d_dX, has_gen);
+        else
+            hipExtLaunchKernelGGL((ya::tile_force<Pt, pw_int, pw_friction>),
+                dim3((n + ya::TILE_BLOCK - 1) / ya::TILE_BLOCK), dim3(ya::TILE_BLOCK), 0, stream, start,
+                stop, 0, n, d_X, d_old_v, d_dX, has_gen);
     }
 };
 

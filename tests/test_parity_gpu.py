@@ -340,3 +340,29 @@ def test_graph_replay_is_the_same_step(oracle, device):
             assert np.array_equal(res[0][1].view(np.uint32), v.view(np.uint32)), model
             for a, b in zip(res[0][2], g):
                 assert np.array_equal(a[:n] if len(a) == n else a, b[:n] if len(b) == n else b)
+
+
+@pytest.mark.parametrize("model,dt", [("springs_tile", 0.001), ("clipped_tile", 0.01), ("relu_po_tile", 0.1),
+                                      ("oscillator_tile", 0.01)])
+def test_many_lanes_per_cell_tile_kernel_bit_exact(oracle, device, model, dt):
+    """Tile_computer::lanes_per_cell = 16 / 64 (ya::tile_force_coop: that many lanes evaluate a
+    cell's pairs, one lane per component sums them in ascending j): bit-identical to the oracle
+    and to the one-thread-per-cell kernel, for 3-, 4- and 5-float points, around the workgroup
+    and tile boundaries."""
+    for n in (1, 2, 3, 4, 5, 15, 16, 17, 63, 64, 65, 129, 511, 512, 513, 800, 1500):
+        res = []
+        for lib, lanes in ((oracle, None), (device, 1), (device, 16), (device, 64)):
+            with Solution(model, n, lib=lib) as s:
+                if lib is oracle:
+                    s.set_reduce_order(1)
+                else:
+                    s.set_param("tile_lanes", lanes)
+                s.random_sphere(0.6, 21)
+                if model == "oscillator_tile":
+                    s.h_X[:n, 3] = np.linspace(0, 1, n, dtype=np.float32)
+                    s.copy_to_device()
+                s.take_step(dt, 2)
+                res.append((s.positions(), s.old_v()[:n]))
+        for X, v in res[1:]:
+            assert np.array_equal(res[0][0].view(np.uint32), X.view(np.uint32)), (model, n)
+            assert np.array_equal(res[0][1].view(np.uint32), v.view(np.uint32)), (model, n)

@@ -41,8 +41,12 @@ def timed(sim, dt, steps, warm=3):
 # cfg 1
 oracle = _ffi.bind(os.path.join(ROOT, "oracle", "_build", "liboracle_models.so"))
 for n in (500, 800):
-    for name, lib in (("device", dev), ("serial host loop (oracle, 1 thread)", oracle)):
+    for name, lib, lanes in (("device, one thread per cell (reference semantics)", dev, 1),
+                             ("device, 64 lanes per cell (opt-in, bit-identical)", dev, 64),
+                             ("serial host loop (oracle, 1 thread)", oracle, None)):
         with Solution("springs_tile", n, lib=lib) as s:
+            if lanes is not None:
+                s.set_param("tile_lanes", lanes)
             s.random_sphere(0.5, 42)
             el = timed(s, 0.001, 100, warm=3 if lib is dev else 0)
             out.append({"config": 1, "workload": f"springs, Tile_solver, {n} cells, 100 steps", "backend": name,
