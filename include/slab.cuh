@@ -1,0 +1,99 @@
+// Grid_solver on several GPUs of one node: z-slabs, one process per GPU (SURVEY.md section 8e,
+// DESIGN.md section 7).  New relative to the reference (single-GPU); everything else about
+// Solution<Pt, Slab_grid_solver> is Solution<Pt, Grid_solver>.
+//
+//     ya_comm* comm;
+//     ya_comm_create_from_env(1, &comm);                       // RANK / WORLD_SIZE / MASTER_* (torchrun, mpirun wrappers ...)
+//     Solution<float3, Slab_grid_solver> cells{n_max, grid_size, cube_size};
+//     ... fill cells.h_X[0 .. n_own) with THIS rank's cells (z in [z_lo, z_hi)), *cells.h_n = n_own ...
+//     cells.copy_to_device();
+//     cells.slab_init(z_lo, z_hi, 1.25f * cube_size, global_ids, n_own);   // global_ids: host array, one per own cell
+//     cells.slab_setup(ya_comm_rank(comm), ya_comm_world(comm), halo_cap, migrate_cap);   // the same on every rank
+//     cells.slab_use_rccl(comm);
+//     for (...) cells.take_step<my_force>(dt);                  // exchanges, all-reduces and migration inside
+//     n_own = cells.slab.n_own;  cells.copy_to_host();          // own cells are h_X[0 .. n_own), their ids: get_own(X, ids)
+//
+// Pairwise functors are called with the cells' GLOBAL ids.  Generic forces see the local arrays
+// (own cells first, then this stage's ghost cells).
+#pragma once
+
+#include "solvers.cuh"
+#include "yalla_hip.h"
+
+namespace ya {
+__global__ void k_slab_mean_from_total(const float* total, int n_floats, float* fix)
+{
+    // fix = sum * float(1. / n): the reference's Pt / n arithmetic (dtypes.cuh:202-217); the cell
+    // count crosses the float all-reduce as two exact pieces (low 12 bits and the rest)
+    const double n = (double)total[n_floats] + 4096. * (double)total[n_floats + 1];
+    const float inv = (float)(1. / n);
+    if (threadIdx.x < 3) fix[threadIdx.x] = total[threadIdx.x] * inv;
+}
+__global__ void k_slab_pack_sum(const float* sum, int n_floats, int n_own, float* out)
+{
+    if ((int)threadIdx.x < n_floats) out[threadIdx.x] = sum[threadIdx.x];
+    if ((int)threadIdx.x == n_floats) {
+        out[n_floats] = (float)(n_own & 4095);
+        out[n_floats + 1] = (float)(n_own >> 12);
+    }
+}
+
+// Backend operations of the slab logic on the device: thin wrappers over the C ABI.
+struct Slab_device_ops {
+    static void* alloc(size_t bytes)
+    {
+        void* p = nullptr;
+        YA_CHECK(ya_malloc(&p, bytes));
+        return p;
+    }
+    static void zero(void* p, size_t bytes) { YA_CHECK(ya_memset_async(p, 0, bytes, nullptr)); }
+    static void release(void* p) { ya_free(p); }
+    static void sync() { YA_CHECK(ya_device_synchronize()); }
+    static void d2h(void* h, const void* d, size_t bytes) { YA_CHECK(ya_memcpy_d2h(h, d, bytes)); }
+    static void h2d(void* d, const void* h, size_t bytes) { YA_CHECK(ya_memcpy_h2d(d, h, bytes)); }
+    static size_t select_workspace_bytes(int n_max) { return ya_select_workspace_bytes(n_max); }
+    static void select_z(const void* X, size_t stride, int n, float z_min, float z_max, int* idx, int* count,
+        int* ws)
+    {
+        YA_CHECK(ya_select_z(X, stride, n, z_min, z_max, idx, count, ws, nullptr));
+    }
+    static void gather_rows(const void* src, size_t row_bytes, const int* idx, const int* count, int cap,
+        void* dst)
+    {
+        YA_CHECK(ya_gather_rows(src, row_bytes, idx, count, cap, dst, nullptr));
+    }
+    static void copy(void* dst, const void* src, size_t bytes)
+    {
+        if (bytes) YA_CHECK(ya_memcpy_d2d_async(dst, src, bytes, nullptr));
+    }
+    static int read_int(const void* d)
+    {
+        int v;
+        YA_CHECK(ya_memcpy_d2h(&v, d, sizeof(int)));
+        return v;
+    }
+    static void append_rows(void* dst, size_t row_bytes, int n_own, const void* lo, const void* hi, int cap,
+        size_t payload_offset, int* n_out)
+    {
+        // a message = 16-byte header {int count}, then the rows
+        YA_CHECK(ya_append_rows(dst, row_bytes, n_own, lo ? (const char*)lo + payload_offset : nullptr,
+            (const int*)lo, hi ? (const char*)hi + payload_offset : nullptr, (const int*)hi, cap, n_out,
+            nullptr));
+    }
+    static void read_ints(const void* d, int k, int* out) { YA_CHECK(ya_memcpy_d2h(out, d, (size_t)k * sizeof(int))); }
+    static void write_int(void* d, int v) { YA_CHECK(ya_memcpy_h2d(d, &v, sizeof(int))); }
+    static void mean_from_total(const float* total, int n_floats, float* fix)
+    {
+        k_slab_mean_from_total<<<1, 64>>>(total, n_floats, fix);
+    }
+    static void pack_sum(const float* sum, int n_floats, int n_own, float* out)
+    {
+        k_slab_pack_sum<<<1, 64>>>(sum, n_floats, n_own, out);
+    }
+};
+}  // namespace ya
+
+#include "slab_logic.inc"
+
+template<typename Pt>
+using Slab_grid_solver = Slab_grid_solver_impl<Pt, ya::Slab_device_ops>;

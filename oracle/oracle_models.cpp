@@ -23,12 +23,12 @@ void ya_harness_random_sphere(float dist_to_nb, C& cells, unsigned seed)
 // Backend operations of the z-slab decomposition, restated serially ("device"
 // memory is host memory).  Same contracts as include/yalla_hip.h's ya_select_z
 // and ya_gather_rows.
-namespace harness_ops {
-inline void* alloc(size_t bytes) { return calloc(1, bytes ? bytes : 4); }
-inline void zero(void* p, size_t bytes) { memset(p, 0, bytes); }
-inline void release(void* p) { free(p); }
-inline size_t select_workspace_bytes(int) { return 4; }
-inline void select_z(const void* X, size_t stride, int n, float z_min, float z_max, int* idx,
+struct Oracle_slab_ops {
+    static void* alloc(size_t bytes) { return calloc(1, bytes ? bytes : 4); }
+    static void zero(void* p, size_t bytes) { memset(p, 0, bytes); }
+    static void release(void* p) { free(p); }
+    static size_t select_workspace_bytes(int) { return 4; }
+    static void select_z(const void* X, size_t stride, int n, float z_min, float z_max, int* idx,
     int* count, int*)
 {
     int m = 0;
@@ -38,7 +38,7 @@ inline void select_z(const void* X, size_t stride, int n, float z_min, float z_m
     }
     *count = m;
 }
-inline void gather_rows(const void* src, size_t row_bytes, const int* idx, const int* count, int cap,
+    static void gather_rows(const void* src, size_t row_bytes, const int* idx, const int* count, int cap,
     void* dst)
 {
     const int m = *count < cap ? *count : cap;
@@ -46,9 +46,9 @@ inline void gather_rows(const void* src, size_t row_bytes, const int* idx, const
         memcpy((char*)dst + (size_t)k * row_bytes, (const char*)src + (size_t)idx[k] * row_bytes,
             row_bytes);
 }
-inline void copy(void* dst, const void* src, size_t bytes) { memmove(dst, src, bytes); }
-inline int read_int(const void* d) { return *(const int*)d; }
-inline void append_rows(void* dst, size_t row_bytes, int n_own, const void* lo, const void* hi,
+    static void copy(void* dst, const void* src, size_t bytes) { memmove(dst, src, bytes); }
+    static int read_int(const void* d) { return *(const int*)d; }
+    static void append_rows(void* dst, size_t row_bytes, int n_own, const void* lo, const void* hi,
     int cap, size_t payload_offset, int* n_out)
 {
     int n = n_own;
@@ -61,22 +61,29 @@ inline void append_rows(void* dst, size_t row_bytes, int n_own, const void* lo, 
     }
     if (n_out) *n_out = n;
 }
-inline void read_ints(const void* d, int k, int* out) { memcpy(out, d, (size_t)k * sizeof(int)); }
-inline void write_int(void* d, int v) { *(int*)d = v; }
+    static void read_ints(const void* d, int k, int* out) { memcpy(out, d, (size_t)k * sizeof(int)); }
+    static void write_int(void* d, int v) { *(int*)d = v; }
 // The cell count travels through the float all-reduce as two exact pieces (low 12 bits and
 // the rest): exact for any total below 2^36 however many ranks add up.
-inline void mean_from_total(const float* total, int n_floats, float* fix)
+    static void mean_from_total(const float* total, int n_floats, float* fix)
 {
     const double n = (double)total[n_floats] + 4096. * (double)total[n_floats + 1];
     const float inv = (float)(1. / n);
     for (int k = 0; k < 3; k++) fix[k] = total[k] * inv;
 }
-inline void pack_sum(const float* sum, int n_floats, int n_own, float* out)
+    static void pack_sum(const float* sum, int n_floats, int n_own, float* out)
 {
     for (int k = 0; k < n_floats; k++) out[k] = sum[k];
     out[n_floats] = (float)(n_own & 4095);
     out[n_floats + 1] = (float)(n_own >> 12);
 }
-}  // namespace harness_ops
+    static void sync() {}
+    static void d2h(void* h, const void* d, size_t bytes) { memcpy(h, d, bytes); }
+    static void h2d(void* d, const void* h, size_t bytes) { memcpy(d, h, bytes); }
+};
+using harness_ops = Oracle_slab_ops;
+
+#include "slab_logic.inc"  // the backend-independent slab logic the HIP engine ships (include/)
+
 
 #include "models_harness.inc"

@@ -28,6 +28,7 @@ def build_oracle():
     srcs = [os.path.join(ORACLE_DIR, f) for f in ("oracle_models.cpp", "yalla_host.hpp")]
     srcs += [os.path.join(ROOT, "yalla_amd", "csrc", f)
              for f in ("model_functors.h", "models_harness.inc")]
+    srcs.append(os.path.join(ROOT, "include", "slab_logic.inc"))
     stale = (not os.path.exists(ORACLE_LIB) or
              any(os.path.getmtime(s) > os.path.getmtime(ORACLE_LIB) for s in srcs))
     if stale:

@@ -38,3 +38,11 @@ def test_polarity_forces_on_the_device():
     """The numeric known answers of the reference's tests/test_polarity.cu evaluated in a
     kernel (device libm), and device against host evaluation of the same code."""
     run("test_polarity_device", "ALL DEVICE POLARITY TESTS PASSED")
+
+
+@pytest.mark.gpu
+def test_header_level_slab_solver():
+    """Solution<Pt, Slab_grid_solver> (include/slab.cuh) as a model program uses it: communicator
+    from the environment, slab_init / slab_setup / slab_use_rccl, take_step; an id-indexed functor
+    with local index != global id; the callback transport.  One rank (one GPU per box)."""
+    run("test_slab_solver", "ALL SLAB SOLVER TESTS PASSED")
