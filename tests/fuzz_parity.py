@@ -27,6 +27,9 @@ def draw(seed):
     radius = (n / 0.64) ** (1 / 3) * dist / 2
     # room to move: dense spring systems overshoot by tens of units within a few steps
     gs = int(2 * (int((radius + 30) / cs) + 2) + rng.integers(0, 3))
+    while gs > 256:  # YA_MAX_GRID_SIZE: binary32 cube ids are exact only up to 256^3 cubes
+        cs *= 2
+        gs = int(2 * (int((radius + 30) / cs) + 2))
     # very dense systems push hard (hundreds of overlapping neighbours): small steps
     dt = 1e-4 if dist < 0.3 else float(rng.choice([0.001, 0.01] if dist < 0.75 else [0.001, 0.01, 0.05]))
     steps = int(rng.integers(1, 4))
