@@ -96,7 +96,7 @@ def parse(argv=None):
     ap.add_argument("--cells", type=int, default=0, help="same as --cells-total (kept for scripts)")
     ap.add_argument("--grid-size", type=int, default=0, help="0 = smallest that fits")
     ap.add_argument("--dist", type=float, default=0.5, help="random_sphere spacing")
-    ap.add_argument("--cpu-steps", type=int, default=2, help="oracle steps for cpu_baseline")
+    ap.add_argument("--cpu-steps", type=int, default=4, help="oracle steps for cpu_baseline (4 steps of 1 M cells: ~12 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--model", default="springs_grid",
                     help="named model of the harness (default: the headline springs_grid)")
