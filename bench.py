@@ -106,7 +106,8 @@ def parse(argv=None):
     ap.add_argument("--slab", action="store_true",
                     help="use the z-slab path (ghost exchange + all-reduce) even on 1 GPU")
     ap.add_argument("--force-variant", type=int, default=2,
-                    help="2 = grid_force_bits (default), 1 = grid_force (byte FIFO), 0 = grid_force_direct (A/B)")
+                    help="2 = grid_force_bits (default), 1 = grid_force (byte FIFO), 0 = grid_force_direct (A/B), "
+                         "3 = grid_force_coop (opt-in: 16 lanes per cell, for <= ~5e4 cells)")
     ap.add_argument("--backend", default="nccl",
                     help="torch.distributed backend for N > 1 / --slab: nccl (= RCCL), or gloo with "
                          "YALLA_BENCH_DEVICE=0 to rehearse the N-rank path on one GPU (RCCL refuses "
@@ -448,6 +449,7 @@ def main(argv=None):
                 "grid_size": gs,
                 "cube_size": 1.0,
                 "step_replayed_as_hipgraph": bool(graph_mode),
+                "force_variant": args.force_variant,
                 "links": n_links if not slab_path else 0,
                 "parallelism": "1 GPU" if world == 1 else
                                f"{world} z-slabs of one {n_total}-cell system, step sequenced "
@@ -459,7 +461,7 @@ def main(argv=None):
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": kernel_name,
+                "kernel": kernel_name if args.force_variant == 2 else {0: "ya::grid_force_direct", 1: "ya::grid_force", 3: "ya::grid_force_coop"}.get(args.force_variant, kernel_name),
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

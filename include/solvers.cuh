@@ -872,8 +872,9 @@ __device__ __forceinline__ void shift_in(unsigned& m, const float d2, const floa
 // One pass: up to three candidate segments [b_r, e_r) of the staged cells (LDS indices;
 // empty if b_r >= e_r), at most PASS_BITS bits after padding each to a multiple of four.
 // shift_r turns an LDS index of segment r into a slot of the sorted arrays.
-template<typename Pt, Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction>
-__device__ __forceinline__ void pass(const Entry<Pt>* __restrict__ sh_e, Lds_word* const words,
+template<typename Pt, Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction, bool STAGE_V>
+__device__ __forceinline__ void pass(const Entry<Pt>* __restrict__ sh_e, const float4* __restrict__ sh_v,
+    Lds_word* const words,
     const int b0, const int e0, const int b1, const int e1, const int b2, const int e2,
     const int shift0, const int shift1, const int shift2, const float4* __restrict__ sorted_v,
     const Pt& Xi, const int i, const float cut2, Pt& F, float3& sum_v, float& sum_friction,
@@ -928,7 +929,10 @@ __device__ __forceinline__ void pass(const Entry<Pt>* __restrict__ sh_e, Lds_wor
         const bool in2 = (q_) >= p2, in1 = (q_) >= p1;                                 \
         const int t = (q_) + (in2 ? d2_ : (in1 ? d1 : d0));                            \
         other_ = sh_e[t];                                                              \
-        v_ = sorted_v[(unsigned)(t + (in2 ? shift2 : (in1 ? shift1 : shift0)))];       \
+        if (STAGE_V)                                                                   \
+            v_ = sh_v[t];                                                              \
+        else                                                                           \
+            v_ = sorted_v[(unsigned)(t + (in2 ? shift2 : (in1 ? shift1 : shift0)))];   \
     }
 #define YA_BITS_PAIR(other_, v_)                                                       \
     {                                                                                  \
@@ -978,7 +982,7 @@ __device__ __forceinline__ void pass(const Entry<Pt>* __restrict__ sh_e, Lds_wor
 }
 }  // namespace bits
 
-template<typename Pt, Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction>
+template<typename Pt, Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction, bool STAGE_V = false>
 __global__ __launch_bounds__(bits::BLOCK) void grid_force_bits(const int n,
     const Entry<Pt>* __restrict__ sorted, const float4* __restrict__ sorted_v,
     const int* __restrict__ cube_id, const int* __restrict__ offs, const int gs,
@@ -989,6 +993,10 @@ __global__ __launch_bounds__(bits::BLOCK) void grid_force_bits(const int n,
     constexpr int CAP = bits::Stage<Pt>::value;
     __shared__ __attribute__((aligned(16))) Entry<Pt> sh_e[CAP + 8];  // slack: whole groups are read
     __shared__ unsigned sh_m[(bits::WORDS + 1) * FB];                // [word][thread], one spare row
+    // STAGE_V (small systems, Grid_computer::forces): old_v of the staged cells in LDS as well.
+    // A launch that cannot fill the chip is one wavefront per SIMD and nothing hides the round
+    // trip to L2 that every interacting pair's old_v otherwise costs.
+    __shared__ float4 sh_v[STAGE_V ? CAP + 8 : 1];
     bits::Lds_word* const words = (bits::Lds_word*)sh_m + threadIdx.x;
 
     const int s0 = xcd_contiguous_tile(blockIdx.x, gridDim.x) * FB;
@@ -1036,6 +1044,7 @@ __global__ __launch_bounds__(bits::BLOCK) void grid_force_bits(const int n,
                 const int shift = v >= v0[2] ? wg_begin[2] - v0[2]
                                              : (v >= v0[1] ? wg_begin[1] - v0[1] : wg_begin[0]);
                 sh_e[t] = sorted[v + shift];
+                if (STAGE_V) sh_v[t] = sorted_v[v + shift];
             }
             __syncthreads();
             // this lane's candidates of the three rows, as LDS indices clipped to the chunk
@@ -1049,7 +1058,7 @@ __global__ __launch_bounds__(bits::BLOCK) void grid_force_bits(const int n,
             const int bits_needed = (max(se[0] - sb[0], 0) + 3 & ~3) + (max(se[1] - sb[1], 0) + 3 & ~3) +
                                     (max(se[2] - sb[2], 0) + 3 & ~3);
             if (!__any(bits_needed > bits::PASS_BITS)) {
-                bits::pass<Pt, pw_int, pw_friction>(sh_e, words, sb[0], se[0], sb[1], se[1], sb[2],
+                bits::pass<Pt, pw_int, pw_friction, STAGE_V>(sh_e, sh_v, words, sb[0], se[0], sb[1], se[1], sb[2],
                     se[2], shift[0], shift[1], shift[2], sorted_v, Xi, gi, cut2, F, sum_v, sum_friction,
                     global_id);
             } else {
@@ -1061,7 +1070,7 @@ __global__ __launch_bounds__(bits::BLOCK) void grid_force_bits(const int n,
                     const int rs = r == 0 ? shift[0] : (r == 1 ? shift[1] : shift[2]);
 #pragma unroll 1
                     for (int b = rb; __any(b < re); b += bits::PASS_BITS)
-                        bits::pass<Pt, pw_int, pw_friction>(sh_e, words, b, min(re, b + bits::PASS_BITS),
+                        bits::pass<Pt, pw_int, pw_friction, STAGE_V>(sh_e, sh_v, words, b, min(re, b + bits::PASS_BITS),
                             0, 0, 0, 0, rs, 0, 0, sorted_v, Xi, gi, cut2, F, sum_v, sum_friction, global_id);
                 }
             }
@@ -1069,6 +1078,287 @@ __global__ __launch_bounds__(bits::BLOCK) void grid_force_bits(const int n,
     }
     if (active) {
         const Pt dX = store_rhs(d_dX, i, has_gen, F, sum_v, sum_friction);
+        if (d_dX_sorted) d_dX_sorted[s] = dX;  // for the sorted-space Euler stage
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// grid_force_coop (opt-in, Grid_computer::force_variant = 3): the grid force with SEVERAL LANES
+// PER CELL, for systems too small to fill the chip with one lane per cell.  A launch of
+// <= 10^5 cells is at most one wavefront per SIMD for the kernels above, each lane working
+// through its ~265 candidates and ~41 hits alone: 52-65 us whatever n is.  Here a 256-thread
+// workgroup owns 256 / LANES consecutive sorted slots (LANES = 16, 8 or 4, chosen from n).  All
+// nine stencil rows are staged in LDS at once when they fit (they do at the densities models
+// run at; otherwise plane by plane, in chunks), then for every cell
+//
+//   A  row by row in the reference's order, each of its lanes tests a contiguous share of the
+//      row's candidates into a bit mask (as grid_force_bits does); a prefix sum of the lanes'
+//      hit counts ranks the hits, which are left as one compact list per cell in LDS, still in
+//      the reference's order;
+//   B  LANES hits at a time, lane l evaluates hit l of the round (distance, functor,
+//      friction) and leaves the pair's terms {F, friction, friction * old_v} in LDS;
+//   C  ONE lane per component adds the round's terms to that component's sum in list order.
+//
+// Every per-cell sum is therefore accumulated in exactly the reference's order and the result
+// is bit-identical to the kernels above.  What changes is the same as for tile_force_coop: the
+// functor is called for one i from several lanes at once, so functors that update per-cell
+// state non-atomically (d_mes_nbs[i] += 1, examples/passive_growth.cu:48-51) must keep one
+// lane per cell.  A, B and C of a cell run inside one wavefront: the only workgroup barriers
+// are those around staging.
+namespace coop {
+constexpr int BLOCK = 256;
+constexpr int MAX_HITS = 96;  // hit-list length per cell; more hits are worked off in parts
+constexpr int STRETCH = 64;   // candidates of a row ranked at a time (<= MAX_HITS, <= 32 per lane)
+// staged cells: nine rows of (the workgroup's cells + two cubes) at rho ~ 10 per cube
+template<typename Pt, int LANES>
+struct Stage {
+    static constexpr int value = (sizeof(Entry<Pt>) <= 16 ? 9 : 5) * (BLOCK / LANES + 34);
+};
+// Lanes per cell for a launch of n cells (MI355X, springs at rho ~ 10, tools/micro/force_ab.hip:
+// 16 lanes 21 us at 10^4 cells, 8 lanes 26 us at 3 * 10^4, 4 lanes 56 us at 10^5, where one lane
+// per cell takes 53, 64 and 66 us); 1 = one lane per cell is as fast or faster.
+inline int lanes_for(const int n) { return n <= 15000 ? 16 : (n <= 40000 ? 8 : (n <= 150000 ? 4 : 1)); }
+// LDS traffic between the lanes of ONE wavefront: the hardware keeps a wavefront's LDS
+// operations in order, the compiler must too.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+}  // namespace coop
+
+template<typename Pt, Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction, int LANES>
+__global__ __launch_bounds__(coop::BLOCK) void grid_force_coop(const int n,
+    const Entry<Pt>* __restrict__ sorted, const float4* __restrict__ sorted_v,
+    const int* __restrict__ cube_id, const int* __restrict__ offs, const int gs,
+    const int n_cubes, const float cut2, Pt* __restrict__ d_dX, const bool has_gen,
+    const int n_active, Pt* __restrict__ d_dX_sorted, const int* __restrict__ global_id)
+{
+    static_assert(LANES == 4 || LANES == 8 || LANES == 16, "lanes per cell");
+    constexpr int CELLS = coop::BLOCK / LANES, MAX_HITS = coop::MAX_HITS;
+    constexpr int CAP = coop::Stage<Pt, LANES>::value;
+    static_assert(CAP < 4096, "a listed hit is row << 12 | LDS index");
+    constexpr int NF = N_floats<Pt>::value;
+    constexpr int NC = NF + 4;  // components summed per cell: F (NF), friction, friction * old_v (3)
+    constexpr int SLOTS = (NC + LANES - 1) / LANES;
+    constexpr bool STAGE_V = LANES >= 8;  // old_v in LDS too where the launch is too small to hide L2
+    __shared__ __attribute__((aligned(16))) Entry<Pt> sh_e[CAP + 4];  // slack: whole groups are read
+    __shared__ float4 sh_v[STAGE_V ? CAP : 1];
+    __shared__ unsigned short sh_hit[CELLS][MAX_HITS];  // row << 12 | LDS index of the hit
+    __shared__ __attribute__((aligned(16))) float sh_term[CELLS][NC][LANES];  // one round's terms
+    __shared__ float sh_sum[CELLS][NC];
+    // row r of the stencil: the workgroup's slot range is [sh_lo[r], sh_lo[r] + sh_len[r]);
+    // a cell's own candidates are the slots [sh_kb[cell][r], sh_ke[cell][r])
+    __shared__ int sh_lo[9], sh_len[9], sh_shift[9], sh_kb[CELLS][9], sh_ke[CELLS][9];
+
+    const int cell = threadIdx.x / LANES, lane = threadIdx.x % LANES;
+    const int s0 = xcd_contiguous_tile(blockIdx.x, gridDim.x) * CELLS;
+    const int s = s0 + cell;
+    bool active = s < n;
+
+    Pt Xi = ya::zero<Pt>();
+    int i = 0, c = 0;
+    if (active) {
+        const Entry<Pt> self = sorted[s];
+        Xi = self.X;
+        i = self.id;
+        c = cube_id[s];
+        active = i < n_active;  // ghost cells of a slab decomposition get no force
+    }
+    if (!__syncthreads_or(active)) return;  // a workgroup of ghosts only
+    const int gi = global_id && active ? global_id[i] : i;
+    // The reference indexes cube_start/end without bounds checks (solvers.cuh:444);
+    // out-of-grid cubes are treated as empty here.
+    for (int r = lane; r < 9; r += LANES) {
+        const int off = stencil_row_offset(r, gs);
+        const int begin = offs[min(max(c + off - 1, 0), n_cubes)];
+        sh_kb[cell][r] = begin;
+        sh_ke[cell][r] = active ? offs[min(max(c + off + 2, 0), n_cubes)] : begin;
+    }
+    if (threadIdx.x < 9) {
+        const int off = stencil_row_offset(threadIdx.x, gs);
+        const int c_lo = cube_id[s0], c_hi = cube_id[min(s0 + CELLS, n) - 1];
+        const int lo = offs[min(max(c_lo + off - 1, 0), n_cubes)];
+        sh_lo[threadIdx.x] = lo;
+        sh_len[threadIdx.x] = offs[min(max(c_hi + off + 2, 0), n_cubes)] - lo;
+    }
+    __syncthreads();
+    int v0[10];  // row r sits at [v0[r], v0[r + 1]) of the nine ranges laid end to end
+    v0[0] = 0;
+#pragma unroll
+    for (int r = 0; r < 9; r++) v0[r + 1] = v0[r] + sh_len[r];
+    if (threadIdx.x < 9) {
+        int mine = 0;
+#pragma unroll
+        for (int r = 0; r < 9; r++) mine = (int)threadIdx.x == r ? v0[r] : mine;
+        sh_shift[threadIdx.x] = sh_lo[threadIdx.x] - mine;  // position in the nine ranges -> sorted slot
+    }
+    __syncthreads();
+
+    float acc[SLOTS];  // this lane's component sums (components lane, lane + LANES, ...)
+#pragma unroll
+    for (int a = 0; a < SLOTS; a++) acc[a] = 0.f;
+
+    const int rows_at_once = v0[9] <= CAP ? 9 : 3;
+#pragma unroll 1
+    for (int g0 = 0; g0 < 9; g0 += rows_at_once) {
+        const int g_end = g0 + rows_at_once;
+        const int g_base = g0 == 0 ? 0 : (g0 == 3 ? v0[3] : v0[6]);
+        const int g_total = (g_end == 9 ? v0[9] : (g_end == 3 ? v0[3] : v0[6])) - g_base;
+#pragma unroll 1
+        for (int chunk = 0; chunk < g_total; chunk += CAP) {
+            const int chunk_n = min(CAP, g_total - chunk);
+            const int base = g_base + chunk;  // where sh_e[0] sits in the nine ranges laid end to end
+            __syncthreads();
+            for (int t = threadIdx.x; t < chunk_n; t += coop::BLOCK) {
+                const int v = base + t;
+                int r = 0;
+#pragma unroll
+                for (int q = 1; q < 9; q++) r += v >= v0[q];
+                const int slot = v + sh_shift[r];
+                sh_e[t] = sorted[slot];
+                if (STAGE_V) sh_v[t] = sorted_v[slot];
+            }
+            __syncthreads();
+
+            // the cell's candidates of row r inside this chunk: LDS indices [sb, sb + len);
+            // the next row's are requested while this one is worked on
+            int r = g0, sb, len, k0 = 0, sb_next, len_next;
+#define YA_COOP_ROW(row_, sb_, len_)                                                   \
+    {                                                                                  \
+        const int rr = min(row_, 8);                                                   \
+        const int shift = sh_shift[rr] + base;                                         \
+        sb_ = max(sh_kb[cell][rr] - shift, 0);                                         \
+        len_ = (row_) < g_end ? max(min(sh_ke[cell][rr] - shift, chunk_n) - sb_, 0) : 0; \
+    }
+            YA_COOP_ROW(g0, sb, len)
+            YA_COOP_ROW(g0 + 1, sb_next, len_next)
+            int listed = 0;  // hits in the cell's list (the same in all its lanes)
+            while (true) {
+                // ---- A: stretches of rows until every cell of the wavefront is through or
+                // its list could overflow ----
+                while (true) {
+                    const int stretch = r < g_end ? min(len - k0, coop::STRETCH) : 0;
+                    const bool go = r < g_end && listed + stretch <= MAX_HITS;
+                    if (!__any(go)) break;
+                    if (go) {
+                        // this lane's share [pb, pe) of the stretch: bit j of the mask, counted
+                        // from the top, is candidate pb + j
+                        const int share = (stretch + LANES - 1) / LANES;
+                        const int pb = sb + k0 + min(lane * share, stretch);
+                        const int pe = sb + k0 + min(lane * share + share, stretch);
+                        unsigned m = 0;
+                        int bits = 0;
+                        for (int t = pb; t < pe; t += 4) {
+                            float4 w[4];
+                            float d2[4];
+#pragma unroll
+                            for (int u = 0; u < 4; u++) w[u] = staged_words(&sh_e[t + u]);
+#pragma unroll
+                            for (int u = 0; u < 4; u++) {
+                                d2[u] = dist2_to(Xi, w[u]);
+                                keep_wide(w[u]);
+                                d2[u] = t + u < pe ? d2[u] : INFINITY;
+                            }
+#pragma unroll
+                            for (int u = 0; u < 4; u++) bits::shift_in(m, d2[u], cut2);
+                            bits += 4;
+                        }
+                        m = bits > 0 ? m << (32 - bits) : 0u;
+                        const int mine = __builtin_popcount(m);
+                        int upto = mine;  // hits of this lane and of the cell's lower lanes
+#pragma unroll
+                        for (int o = 1; o < LANES; o <<= 1) {
+                            const int up = __shfl_up(upto, o, LANES);
+                            upto += lane >= o ? up : 0;
+                        }
+                        int rank = listed + upto - mine;
+                        listed += __shfl(upto, LANES - 1, LANES);
+                        while (m != 0) {
+                            const int pos = __builtin_clz(m);
+                            m &= 0x7fffffffu >> pos;
+                            sh_hit[cell][rank++] = (unsigned short)((r << 12) | (pb + pos));
+                        }
+                        k0 += stretch;
+                        while (k0 >= len && r < g_end) {
+                            r++;
+                            k0 = 0;
+                            sb = sb_next;
+                            len = len_next;
+                            YA_COOP_ROW(r + 1, sb_next, len_next)
+                        }
+                    }
+                }
+                if (!__any(listed > 0)) break;  // every cell is through all rows
+                coop::wave_sync();
+                // ---- B and C, LANES hits per round.  Lanes past the end of the list leave zero
+                // terms: a sum that starts at +0 never is -0, so adding +0 changes no bit ----
+                for (int h0 = 0; __any(h0 < listed); h0 += LANES) {
+                    const int h = h0 + lane;
+                    Pt f = ya::zero<Pt>();
+                    float friction = 0;
+                    float4 v{0.f, 0.f, 0.f, 0.f};
+                    if (h < listed) {
+                        const int e = sh_hit[cell][h];
+                        const int t = e & 0xfff;
+                        const Entry<Pt> other = sh_e[t];
+                        if (STAGE_V)
+                            v = sh_v[t];
+                        else
+                            v = sorted_v[(unsigned)(t + base + sh_shift[e >> 12])];
+                        Pt rr = Xi - other.X;
+                        float dist = dist3(rr.x, rr.y, rr.z);
+                        const int j = global_id ? global_id[other.id] : other.id;
+                        f = pw_int(Xi, rr, dist, gi, j);
+                        friction = pw_friction(Xi, rr, dist, gi, j);
+                    }
+#pragma unroll
+                    for (int q = 0; q < NF; q++) sh_term[cell][q][lane] = field(f, q);
+                    sh_term[cell][NF][lane] = friction;
+                    sh_term[cell][NF + 1][lane] = friction * v.x;
+                    sh_term[cell][NF + 2][lane] = friction * v.y;
+                    sh_term[cell][NF + 3][lane] = friction * v.z;
+                    coop::wave_sync();
+#pragma unroll
+                    for (int a = 0; a < SLOTS; a++) {
+                        const int q = lane + LANES * a;
+                        if (q < NC) {
+                            float sum = acc[a];
+                            const float4* terms = reinterpret_cast<const float4*>(&sh_term[cell][q][0]);
+                            const float4* frictions = reinterpret_cast<const float4*>(&sh_term[cell][NF][0]);
+                            const bool conditional = q > NF;  // the old_v term only where the friction
+#pragma unroll                                                // is not zero (solvers.cuh:454-458)
+                            for (int u = 0; u < LANES / 4; u++) {
+                                const float4 p = terms[u];
+                                const float4 fr = conditional ? frictions[u] : float4{1.f, 1.f, 1.f, 1.f};
+                                sum = fr.x != 0 ? sum + p.x : sum;
+                                sum = fr.y != 0 ? sum + p.y : sum;
+                                sum = fr.z != 0 ? sum + p.z : sum;
+                                sum = fr.w != 0 ? sum + p.w : sum;
+                            }
+                            acc[a] = sum;
+                        }
+                    }
+                    coop::wave_sync();
+                }
+                listed = 0;
+            }
+#undef YA_COOP_ROW
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < SLOTS; a++) {
+        const int q = lane + LANES * a;
+        if (q < NC) sh_sum[cell][q] = acc[a];
+    }
+    coop::wave_sync();
+    if (active && lane == 0) {
+        Pt F;
+#pragma unroll
+        for (int q = 0; q < NF; q++) field(F, q) = sh_sum[cell][q];
+        const Pt dX = store_rhs(d_dX, i, has_gen, F,
+            float3{sh_sum[cell][NF + 1], sh_sum[cell][NF + 2], sh_sum[cell][NF + 3]}, sh_sum[cell][NF]);
         if (d_dX_sorted) d_dX_sorted[s] = dX;  // for the sorted-space Euler stage
     }
 }
@@ -1781,7 +2071,13 @@ class Grid_computer {
 public:
     float cube_size;
     ya::Profiler profiler;
-    int force_variant = 2;  // 2 = grid_force_bits (bit stream, default), 1 = grid_force (byte FIFO), 0 = grid_force_direct (A/B)
+    // 2 = grid_force_bits (bit stream, default), 1 = grid_force (byte FIFO), 0 = grid_force_direct (A/B);
+    // 3 = grid_force_coop below ~1.5 * 10^5 cells (16, 8 or 4 lanes per cell, more the smaller the
+    // system), grid_force_bits above: for models whose functors keep no per-cell state without
+    // atomics (bit-identical results; see the kernel's comment)
+    int force_variant = 2;
+    int coop_lanes = 0;            // force_variant 3: 0 = from n (ya::coop::lanes_for), or 4 / 8 / 16
+    int stage_v_max = 130000;      // grid_force_bits keeps old_v in LDS too up to this many cells
     Grid_computer(int n_max, int grid_size = 50, float cube_size = 1)
         : cube_size{cube_size}, grid{n_max, grid_size}
     {
@@ -1841,7 +2137,24 @@ protected:
             __VA_ARGS__);                                                                     \
     else                                                                                      \
         hipLaunchKernelGGL((kernel_), dim3(grid_), dim3(block_), 0, stream, __VA_ARGS__)
-        if (force_variant == 2) {
+        const int lanes = force_variant == 3 ? (coop_lanes ? coop_lanes : ya::coop::lanes_for(n)) : 1;
+#define YA_COOP_LAUNCH(lanes_)                                                                 \
+    YA_FORCE_LAUNCH((ya::grid_force_coop<Pt, pw_int, pw_friction, lanes_>),                    \
+        (n + ya::coop::BLOCK / lanes_ - 1) / (ya::coop::BLOCK / lanes_), ya::coop::BLOCK, n,   \
+        d_cells, d_cells_v, (const int*)grid.d_cube_id, grid.offsets(), grid.grid_size,        \
+        grid.n_cubes, cut2, d_dX, has_gen, n_active, d_dX_in_cell_order, (const int*)d_global_id)
+        if (lanes == 16) {
+            YA_COOP_LAUNCH(16);
+        } else if (lanes == 8) {
+            YA_COOP_LAUNCH(8);
+        } else if (lanes == 4) {
+            YA_COOP_LAUNCH(4);
+        } else if (force_variant >= 2 && n <= stage_v_max) {
+            YA_FORCE_LAUNCH((ya::grid_force_bits<Pt, pw_int, pw_friction, true>),
+                (n + ya::bits::BLOCK - 1) / ya::bits::BLOCK, ya::bits::BLOCK, n, d_cells, d_cells_v,
+                (const int*)grid.d_cube_id, grid.offsets(), grid.grid_size, grid.n_cubes, cut2, d_dX,
+                has_gen, n_active, d_dX_in_cell_order, (const int*)d_global_id);
+        } else if (force_variant >= 2) {
             YA_FORCE_LAUNCH((ya::grid_force_bits<Pt, pw_int, pw_friction>),
                 (n + ya::bits::BLOCK - 1) / ya::bits::BLOCK, ya::bits::BLOCK, n, d_cells, d_cells_v,
                 (const int*)grid.d_cube_id, grid.offsets(), grid.grid_size, grid.n_cubes, cut2, d_dX,
@@ -1855,6 +2168,7 @@ protected:
                 d_cells_v, (const int*)grid.d_cube_id, grid.offsets(), grid.grid_size, grid.n_cubes,
                 cut2, d_dX, has_gen, n_active, d_dX_in_cell_order, (const int*)d_global_id);
         }
+#undef YA_COOP_LAUNCH
 #undef YA_FORCE_LAUNCH
     }
     // The part of the first stage's grid build that can be queued before the host knows

@@ -36,8 +36,14 @@ def draw(seed):
     # force kernel of the device engine: mostly the default bit-stream kernel, sometimes the
     # byte-FIFO one or the direct one (drawn last: the earlier draws keep their round-1 values)
     variant = int(rng.choice([2, 2, 2, 1, 0])) if model.endswith("_grid") else 2
+    # then (drawn after everything else again): a third of the grid cases through grid_force_coop
+    # with 4, 8 or 16 lanes per cell, and grid_force_bits with old_v staged in LDS or not
+    lanes = int(rng.choice([0, 0, 0, 0, 4, 8, 16, 16]))
+    stage_v = bool(rng.random() < 0.5)
+    if lanes and model.endswith("_grid"):
+        variant = 3
     return dict(model=model, n=n, gs=max(gs, 8), cs=cs, dist=dist, seed=int(seed), dt=dt, steps=steps,
-                variant=variant)
+                variant=variant, lanes=lanes if variant == 3 else 0, stage_v=stage_v)
 
 
 def run_case(oracle, device, c):
@@ -48,6 +54,8 @@ def run_case(oracle, device, c):
                 assert s.set_reduce_order(1) == 0
             elif c["model"].endswith("_grid"):
                 s.set_param("force_variant", c.get("variant", 2))
+                s.set_param("coop_lanes", c.get("lanes", 0))
+                s.set_param("stage_v_max", 1 << 30 if c.get("stage_v") else 0)
             s.random_sphere(c["dist"], c["seed"])
             s.take_step(c["dt"], c["steps"])
             out.append((s.positions(), s.old_v()[:c["n"]],

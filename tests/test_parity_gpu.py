@@ -69,20 +69,45 @@ def test_other_functors_bit_exact(oracle, device, model):
     assert np.array_equal(vo.view(np.uint32), vd.view(np.uint32))
 
 
-def test_all_three_force_kernels_agree(oracle, device):
-    """grid_force_bits (bit-stream hit list, the default), grid_force (byte FIFO) and
-    grid_force_direct (the reference's structure) are the same sums in the same order:
-    bit-identical to each other and to the oracle."""
+# (force_variant, coop_lanes, stage_v_max): grid_force_direct, grid_force, grid_force_bits with
+# old_v from global memory and from LDS, grid_force_coop with 16, 8 and 4 lanes per cell
+FORCE_KERNELS = [(0, 0, 0), (1, 0, 0), (2, 0, 0), (2, 0, 1 << 30), (3, 16, 0), (3, 8, 0), (3, 4, 0)]
+
+
+def select_kernel(s, kernel):
+    variant, lanes, stage_v_max = kernel
+    s.set_param("force_variant", variant)
+    s.set_param("coop_lanes", lanes)
+    s.set_param("stage_v_max", stage_v_max)
+
+
+def test_all_force_kernels_agree(oracle, device):
+    """grid_force_bits (bit-stream hit list, the default; old_v from global memory or LDS),
+    grid_force (byte FIFO), grid_force_direct (the reference's structure) and grid_force_coop
+    (several lanes per cell) are the same sums in the same order: bit-identical to each other
+    and to the oracle."""
     n = 30000
     res = []
-    for variant in (0, 1, 2):
+    for kernel in FORCE_KERNELS:
         (Xo, vo, _), (Xd, vd, _) = run_both(
             oracle, device, "springs_grid", n, 50, 1.0, 0.5, 4, 0.001, 2,
-            setup=lambda s: s.set_param("force_variant", variant) if s.lib is device else None)
-        assert np.array_equal(Xo.view(np.uint32), Xd.view(np.uint32)), variant
+            setup=lambda s: select_kernel(s, kernel) if s.lib is device else None)
+        assert np.array_equal(Xo.view(np.uint32), Xd.view(np.uint32)), kernel
+        assert np.array_equal(vo.view(np.uint32), vd.view(np.uint32)), kernel
         res.append(Xd)
-    assert np.array_equal(res[0].view(np.uint32), res[1].view(np.uint32))
-    assert np.array_equal(res[0].view(np.uint32), res[2].view(np.uint32))
+    for X in res[1:]:
+        assert np.array_equal(res[0].view(np.uint32), X.view(np.uint32))
+
+
+def test_cooperative_kernel_picks_its_lanes_from_n(oracle, device):
+    """force_variant 3 with the lanes per cell left to ya::coop::lanes_for: 16, 8 and 4 lanes and,
+    above 1.5 * 10^5 cells, the one-lane kernel -- always the oracle's bits."""
+    for n, gs in ((9000, 40), (30000, 50), (100000, 64), (160000, 64)):
+        (Xo, vo, _), (Xd, vd, _) = run_both(
+            oracle, device, "springs_grid", n, gs, 1.0, 0.5, 4, 0.001, 1,
+            setup=lambda s: s.set_param("force_variant", 3) if s.lib is device else None)
+        assert np.array_equal(Xo.view(np.uint32), Xd.view(np.uint32)), n
+        assert np.array_equal(vo.view(np.uint32), vd.view(np.uint32)), n
 
 
 @pytest.mark.parametrize("model,n,dist,cube", [
@@ -92,13 +117,13 @@ def test_all_three_force_kernels_agree(oracle, device):
     ("relu_cell_grid", 4000, 0.5, 1.0),    # 32-byte entries
 ])
 def test_force_kernels_agree_on_dense_rows(device, model, n, dist, cube):
-    """The three kernels against each other where a lane's row exceeds one pass of the bit
-    stream (and the plane exceeds the staging capacity): bit-identical."""
+    """The kernels against each other where a lane's row exceeds one pass of the bit stream,
+    the plane exceeds the staging capacity and a cell's hits exceed its list: bit-identical."""
     res = []
-    for variant in (0, 1, 2):
+    for kernel in FORCE_KERNELS:
         with Solution(model, n, 50, cube, lib=device) as s:
             s.random_sphere(dist, 5)
-            s.set_param("force_variant", variant)
+            select_kernel(s, kernel)
             s.take_step(0.0005, 2)
             res.append((s.positions(), s.old_v()))
     for X, v in res[1:]:

@@ -3,6 +3,7 @@
 // Builds the grid once on a state that `warm` take_steps have relaxed, then times
 // variant 1 (grid_force, byte FIFO) and variant 2 (grid_force_bits, compiled with this
 // executable's -DYA_BITS_BLOCK / -DYA_BITS_POPS / -DYA_MASK_WORDS flags) in interleaved rounds with HIP events,
+// (AB_BASE / AB_TEST select other pairs: 3 = grid_force_coop, 12 = grid_force_bits with old_v in LDS)
 // and compares their outputs (d_dX by id and d_dX in sorted order) bit for bit.
 // One JSON line per run; tools/micro/force_ab.sh builds and runs a set of configurations.
 #include <algorithm>
@@ -34,7 +35,12 @@ struct Probe : public Solution<Pt, Grid_solver> {
     void build(int n) { this->grid.build_sorted(n, this->d_X, this->d_old_v, this->cube_size, this->d_sorted, this->d_sorted_v); }
     void run(int n, int variant, Pt* out, Pt* out_sorted)
     {
-        this->force_variant = variant;
+        // variants >= 10: variant - 10 with old_v staged in LDS whatever n is; < 10: never staged
+        this->force_variant = variant % 10;
+#ifdef YA_COOP_LANES
+        this->coop_lanes = YA_COOP_LANES;  // variant 3: fixed instead of chosen from n
+#endif
+        this->stage_v_max = variant >= 10 ? 2000000000 : 0;
         this->template forces<models::spring, friction_w_neighbour<Pt>>(
             n, this->d_sorted, this->d_sorted_v, out, false, n, out_sorted);
     }
