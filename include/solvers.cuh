@@ -956,25 +956,23 @@ __device__ __forceinline__ void pass(const Entry<Pt>* __restrict__ sh_e, const f
         left -= refill ? 1 : 0;
         nxt = *rp;
         if (cur != 0) {
-            const int pos = __builtin_clz(cur);
-            cur &= 0x7fffffffu >> pos;
-            Entry<Pt> other;
-            float4 v;
-            YA_BITS_LOAD(wbase + pos, other, v)
-            if (YA_BITS_POPS == 2) {
-                // a second hit of the same word, if there is one: its loads are issued before
-                // the first hit's arithmetic (without one, the first hit's are repeated)
-                const bool second = cur != 0;
-                const int pos_b = second ? __builtin_clz(cur) : pos;
-                cur = second ? cur & (0x7fffffffu >> pos_b) : cur;
-                Entry<Pt> other_b;
-                float4 v_b;
-                YA_BITS_LOAD(wbase + pos_b, other_b, v_b)
-                YA_BITS_PAIR(other, v)
-                if (second) YA_BITS_PAIR(other_b, v_b)
-            } else {
-                YA_BITS_PAIR(other, v)
+            // up to YA_BITS_POPS hits of the word: the loads of the later ones are issued before
+            // the first one's arithmetic (a hit that is not there repeats the one before it)
+            int pos[YA_BITS_POPS];
+            bool have[YA_BITS_POPS];
+            Entry<Pt> other[YA_BITS_POPS];
+            float4 v[YA_BITS_POPS];
+#pragma unroll
+            for (int u = 0; u < YA_BITS_POPS; u++) {
+                have[u] = cur != 0;
+                pos[u] = have[u] ? __builtin_clz(cur) : pos[u > 0 ? u - 1 : 0];
+                cur = have[u] ? cur & (0x7fffffffu >> pos[u]) : cur;
+                YA_BITS_LOAD(wbase + pos[u], other[u], v[u])
             }
+            YA_BITS_PAIR(other[0], v[0])
+#pragma unroll
+            for (int u = 1; u < YA_BITS_POPS; u++)
+                if (have[u]) YA_BITS_PAIR(other[u], v[u])
         }
     }
 #undef YA_BITS_LOAD
