@@ -67,6 +67,18 @@ MODELS = {
 }
 
 
+def force_kernel_label(default_name, variant, n):
+    """The force kernel a launch of n cells goes to (Grid_computer::forces, ya::coop::lanes_for)."""
+    if variant == 2 or "grid_force_bits" not in default_name:
+        return default_name
+    if variant == 3:
+        lanes = 16 if n <= 15000 else 8 if n <= 40000 else 4 if n <= 150000 else 1
+        if lanes == 1:
+            return default_name
+        return default_name.replace("grid_force_bits<", "grid_force_coop<").replace(">", f", {lanes} lanes per cell>")
+    return default_name.replace("grid_force_bits", {0: "grid_force_direct", 1: "grid_force"}[variant])
+
+
 def force_bytes_per_cell(n_floats):
     """Algorithmic bytes of one force launch per cell (SURVEY.md §8(d) force row):
     r P + V + 2I, w P with P = 4 n_floats, V = 12, I = 4."""
@@ -461,7 +473,7 @@ def main(argv=None):
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": kernel_name if args.force_variant == 2 else {0: "ya::grid_force_direct", 1: "ya::grid_force", 3: "ya::grid_force_coop"}.get(args.force_variant, kernel_name),
+                "kernel": force_kernel_label(kernel_name, args.force_variant, n_total // world),
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

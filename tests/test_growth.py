@@ -107,3 +107,29 @@ def test_branching_device_matches_oracle_lockstep(oracle, device):
     assert grown
     so.close()
     sd.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lanes", [4, 8, 16])
+def test_branching_with_several_lanes_per_cell(device, lanes):
+    """Config 3's functor counts neighbours with atomicAdd (branching.cu:105-107), so it may be
+    called for one cell from several lanes at once: grid_force_coop (force_variant 3) gives the
+    default kernel's positions, polarities, morphogens, cell counts, types and counters bit for
+    bit, through cell division (n grows between steps)."""
+    runs = []
+    for variant in (2, 3):
+        s, _ = branching_case.setup(device, n_0=3000, n_max=6000)
+        s.set_param("force_variant", variant)
+        s.set_param("coop_lanes", lanes if variant == 3 else 0)
+        s.set_param("prolif_rate", 1.0)
+        counts = []
+        for _ in range(8):
+            s.take_step(0.2)
+            counts.append(s.get_d_n())
+        n = counts[-1]
+        runs.append((counts, s.positions(), s.get_prop("type", n), s.get_prop("mes_nbs", n), s.get_prop("epi_nbs", n)))
+        s.close()
+    (counts_a, Xa, ta, ma, ea), (counts_b, Xb, tb, mb, eb) = runs
+    assert counts_a == counts_b and counts_a[-1] > 3000
+    assert np.array_equal(Xa.view(np.uint32), Xb.view(np.uint32))
+    assert np.array_equal(ta, tb) and np.array_equal(ma, mb) and np.array_equal(ea, eb)

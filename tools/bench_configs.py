@@ -65,14 +65,22 @@ out.append({"config": 2, "workload": "sorting (differential_adhesion), Grid_solv
             "cell_updates_per_s": line["value"], "ms_per_step": line["ms_per_step"],
             "force_launch_us": line["roofline"]["avg_launch_us"]})
 
-# cfg 3
-s, _ = branching_case.setup(dev, n_0=100_000, n_max=140_000)
-s.set_param("prolif_rate", 0.0)
-el = timed(s, 0.2, 22)
-out.append({"config": 3, "workload": "branching model (Cell, epi_turing_mes_noturing + reset_nbs), Grid_solver gs 100, "
-                                     "100 000-cell snapshot, division frozen, 22 steps of dt 0.2",
-            "cell_updates_per_s": 100_000 * 22 / el, "ms_per_step": el / 22 * 1e3})
-s.close()
+line = bench_py("--model", "sorting_grid", "--cells-total", "10000", "--dt", "0.05", "--steps", "300",
+                "--force-variant", "3")
+out.append({"config": 2, "workload": "the same with force_variant = 3 (grid_force_coop, 16 lanes per cell; opt-in, bit-identical)",
+            "cell_updates_per_s": line["value"], "ms_per_step": line["ms_per_step"],
+            "force_launch_us": line["roofline"]["avg_launch_us"]})
+
+# cfg 3 (its functor counts neighbours with atomicAdd, branching.cu:105-107: several lanes per cell are allowed)
+for variant, label in ((2, ""), (3, "; force_variant = 3 (grid_force_coop, 4 lanes per cell; opt-in)")):
+    s, _ = branching_case.setup(dev, n_0=100_000, n_max=140_000)
+    s.set_param("prolif_rate", 0.0)
+    s.set_param("force_variant", variant)
+    el = timed(s, 0.2, 22)
+    out.append({"config": 3, "workload": "branching model (Cell, epi_turing_mes_noturing + reset_nbs), Grid_solver gs 100, "
+                                         "100 000-cell snapshot, division frozen, 22 steps of dt 0.2" + label,
+                "cell_updates_per_s": 100_000 * 22 / el, "ms_per_step": el / 22 * 1e3})
+    s.close()
 
 # cfg 4
 target = 1_000_000
