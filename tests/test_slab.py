@@ -27,10 +27,14 @@ def reference_run(lib, n, gs, dist, seed, dt, steps, tree=False, model="springs_
         return X0, s.positions()
 
 
-def slab_run(lib, X0, world, gs, dt, steps, device="cpu", migrate_every=1, model="springs_grid"):
+def slab_run(lib, X0, world, gs, dt, steps, device="cpu", migrate_every=1, model="springs_grid",
+             force_variant=None):
     bounds = slab_mod.slab_bounds(X0[:, 2], world)
     slabs = [slab_mod.Slab(model, X0, r, world, bounds, gs, lib=lib, device=device)
              for r in range(world)]
+    if force_variant is not None:
+        for s in slabs:
+            s.sim.set_param("force_variant", force_variant)
     if model.startswith("sorting"):
         for s in slabs:
             s.sim.set_param("n_cells", len(X0))  # types split at the GLOBAL id n / 2 (sorting.cu:24)
@@ -183,6 +187,16 @@ def test_rccl_communicator_single_rank(device):
 def test_slabs_match_undivided_system_device(device, world):
     moved = check(device, 40000, world, 6, 0.004, device="hip")
     assert moved >= 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", ["springs_grid", "sorting_grid"])
+def test_slabs_with_several_lanes_per_cell(device, model):
+    """grid_force_coop in a slab (ghost cells get no force, functors get global ids): the same
+    three slabs stepped with force_variant 3 and with the default kernel end bit-identical."""
+    X0, _ = reference_run(device, 30000, 50, 0.5, 3, 0.002, 0, model=model)
+    runs = [slab_run(device, X0, 3, 50, 0.002, 6, "hip", model=model, force_variant=v)[0] for v in (2, 3)]
+    assert np.array_equal(runs[0].view(np.uint32), runs[1].view(np.uint32))
 
 
 @pytest.mark.gpu
