@@ -396,10 +396,12 @@ __global__ __launch_bounds__(256) void tile_force_coop(const int n,
 #pragma unroll
                 for (int c = 0; c < NF; c++) sh_part[cell][c][jj] = field(f, c);
                 sh_part[cell][NF][jj] = friction;
+                // the old_v term only where the friction is not zero (solvers.cuh:312-316): a +0
+                // term instead changes no bit of a sum that started at +0 (such a sum never is -0)
                 const float3 v = sh_v[jj];
-                sh_part[cell][NF + 1][jj] = friction * v.x;
-                sh_part[cell][NF + 2][jj] = friction * v.y;
-                sh_part[cell][NF + 3][jj] = friction * v.z;
+                sh_part[cell][NF + 1][jj] = friction != 0 ? friction * v.x : 0.f;
+                sh_part[cell][NF + 2][jj] = friction != 0 ? friction * v.y : 0.f;
+                sh_part[cell][NF + 3][jj] = friction != 0 ? friction * v.z : 0.f;
             }
         }
         __syncthreads();
@@ -411,26 +413,20 @@ __global__ __launch_bounds__(256) void tile_force_coop(const int n,
                 // sixteen terms per trip: four 16-byte LDS reads in flight, then the adds in order
                 float sum = acc[a];
                 const float4* terms = reinterpret_cast<const float4*>(&sh_part[cell][c][0]);
-                const float4* frictions = reinterpret_cast<const float4*>(&sh_part[cell][NF][0]);
-                const bool conditional = c > NF;  // the old_v term only where the friction is not zero
-                int jj = 0;                        // (solvers.cuh:312-316)
+                int jj = 0;
                 for (; jj + 16 <= n_tile; jj += 16) {
-                    float4 p[4], fr[4];
+                    float4 p[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) p[u] = terms[jj / 4 + u];
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
-                        p[u] = terms[jj / 4 + u];
-                        fr[u] = conditional ? frictions[jj / 4 + u] : float4{1.f, 1.f, 1.f, 1.f};
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        sum = fr[u].x != 0 ? sum + p[u].x : sum;
-                        sum = fr[u].y != 0 ? sum + p[u].y : sum;
-                        sum = fr[u].z != 0 ? sum + p[u].z : sum;
-                        sum = fr[u].w != 0 ? sum + p[u].w : sum;
+                        sum += p[u].x;
+                        sum += p[u].y;
+                        sum += p[u].z;
+                        sum += p[u].w;
                     }
                 }
-                for (; jj < n_tile; jj++)
-                    if (!conditional || sh_part[cell][NF][jj] != 0) sum += sh_part[cell][c][jj];
+                for (; jj < n_tile; jj++) sum += sh_part[cell][c][jj];
                 acc[a] = sum;
             }
         }
@@ -1314,9 +1310,10 @@ __global__ __launch_bounds__(coop::BLOCK) void grid_force_coop(const int n,
 #pragma unroll
                     for (int q = 0; q < NF; q++) sh_term[cell][q][lane] = field(f, q);
                     sh_term[cell][NF][lane] = friction;
-                    sh_term[cell][NF + 1][lane] = friction * v.x;
-                    sh_term[cell][NF + 2][lane] = friction * v.y;
-                    sh_term[cell][NF + 3][lane] = friction * v.z;
+                    // the old_v term only where the friction is not zero (solvers.cuh:454-458)
+                    sh_term[cell][NF + 1][lane] = friction != 0 ? friction * v.x : 0.f;
+                    sh_term[cell][NF + 2][lane] = friction != 0 ? friction * v.y : 0.f;
+                    sh_term[cell][NF + 3][lane] = friction != 0 ? friction * v.z : 0.f;
                     coop::wave_sync();
 #pragma unroll
                     for (int a = 0; a < SLOTS; a++) {
@@ -1324,16 +1321,13 @@ __global__ __launch_bounds__(coop::BLOCK) void grid_force_coop(const int n,
                         if (q < NC) {
                             float sum = acc[a];
                             const float4* terms = reinterpret_cast<const float4*>(&sh_term[cell][q][0]);
-                            const float4* frictions = reinterpret_cast<const float4*>(&sh_term[cell][NF][0]);
-                            const bool conditional = q > NF;  // the old_v term only where the friction
-#pragma unroll                                                // is not zero (solvers.cuh:454-458)
+#pragma unroll
                             for (int u = 0; u < LANES / 4; u++) {
                                 const float4 p = terms[u];
-                                const float4 fr = conditional ? frictions[u] : float4{1.f, 1.f, 1.f, 1.f};
-                                sum = fr.x != 0 ? sum + p.x : sum;
-                                sum = fr.y != 0 ? sum + p.y : sum;
-                                sum = fr.z != 0 ? sum + p.z : sum;
-                                sum = fr.w != 0 ? sum + p.w : sum;
+                                sum += p.x;
+                                sum += p.y;
+                                sum += p.z;
+                                sum += p.w;
                             }
                             acc[a] = sum;
                         }
