@@ -1109,8 +1109,8 @@ struct Stage {
     static constexpr int value = (sizeof(Entry<Pt>) <= 16 ? 9 : 5) * (BLOCK / LANES + 34);
 };
 // Lanes per cell for a launch of n cells (MI355X, springs at rho ~ 10, tools/micro/force_ab.hip:
-// 16 lanes 21 us at 10^4 cells, 8 lanes 26 us at 3 * 10^4, 4 lanes 56 us at 10^5, where one lane
-// per cell takes 53, 64 and 66 us); 1 = one lane per cell is as fast or faster.
+// 16 lanes 19 us at 10^4 cells, 8 lanes 24 us at 3 * 10^4, 4 lanes 55 us at 10^5, where one lane
+// per cell takes 53, 64 and 65 us); 1 = one lane per cell is as fast or faster.
 inline int lanes_for(const int n) { return n <= 15000 ? 16 : (n <= 40000 ? 8 : (n <= 150000 ? 4 : 1)); }
 // LDS traffic between the lanes of ONE wavefront: the hardware keeps a wavefront's LDS
 // operations in order, the compiler must too.
