@@ -235,15 +235,21 @@ def launch_ranks(args, argv):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if rank == 0 else sys.stderr))
-    line, _ = procs[0].communicate()
-    codes = [procs[0].returncode]
-    deadline = time.time() + 120
-    for p in procs[1:]:
-        try:
-            codes.append(p.wait(timeout=max(1.0, deadline - time.time())))
-        except subprocess.TimeoutExpired:
-            p.kill()   # the exact process we started
-            codes.append(-9)
+    # rank 0's stdout is one JSON line (small: no pipe can fill up); poll all ranks so that one
+    # that dies takes the others -- blocked in a collective -- down with it instead of hanging
+    failed = False
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):
+            failed = True
+            break
+        time.sleep(0.2)
+    if failed:
+        time.sleep(2.0)  # let the others report their own error first
+        for p in procs:
+            if p.poll() is None:
+                p.kill()   # the exact processes we started
+    line = procs[0].stdout.read()
+    codes = [p.wait() for p in procs]
     sys.stdout.write(line.decode())
     sys.stdout.flush()
     if any(codes):
@@ -264,6 +270,8 @@ def main(argv=None):
     if "YALLA_BENCH_DEVICE" in os.environ:  # testing only: several ranks on one GPU
         local_rank = int(os.environ["YALLA_BENCH_DEVICE"])
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if os.environ.get("YALLA_BENCH_TEST_HANG_RANK") == str(rank):  # testing only: a rank stuck in a collective
+        time.sleep(600)
     if world != args.gpus:
         sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}\n")
         args.gpus = world

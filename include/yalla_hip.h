@@ -184,7 +184,8 @@ typedef struct ya_comm ya_comm;
 
 /* Rank 0: a fresh unique id (ncclGetUniqueId) to hand to every rank. */
 int ya_comm_unique_id(void* id_out_128_bytes);
-/* Every rank, on its current device: ncclCommInitRank.  world == 1 needs no id and no RCCL. */
+/* Every rank, on its current device: ncclCommInitRank.  world == 1 needs no id and no RCCL
+ * (id NULL); world == 1 WITH an id makes a real one-rank RCCL communicator. */
 int ya_comm_create(const void* id_128_bytes, int rank, int world, ya_comm** out);
 /* The same with the id passed from rank 0 over TCP: RANK, WORLD_SIZE, MASTER_ADDR and
  * MASTER_PORT from the environment (the variables torch.distributed.run sets); rank 0 listens
@@ -198,6 +199,9 @@ int ya_comm_world(const ya_comm* comm);
  * (the first and last rank have one neighbour; their other buffers may be NULL). */
 int ya_comm_exchange(ya_comm* comm, const void* d_send_lo, void* d_recv_lo, const void* d_send_hi,
     void* d_recv_hi, size_t bytes, void* stream);
+/* `bytes` bytes of d_send to this rank itself (one RCCL group of ncclSend + ncclRecv): what a
+ * one-GPU machine can check of the binding ya_comm_exchange uses. */
+int ya_comm_self_exchange(ya_comm* comm, const void* d_send, void* d_recv, size_t bytes, void* stream);
 /* In-place sum of `count` floats over all ranks (ncclAllReduce) on `stream`. */
 int ya_comm_allreduce_sum(ya_comm* comm, float* d_buf, int count, void* stream);
 /* The same on host memory through the devices (a bounce buffer): for the few control values a

@@ -30,6 +30,20 @@ def test_bench_starts_its_own_ranks():
     assert proc.stdout.strip() == ""
 
 
+def test_a_dead_rank_takes_the_others_down():
+    """One rank fails while the other is stuck (as in a collective its peer never joins): the
+    parent must end the stuck one and report, not hang until the driver's limit."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["YALLA_BENCH_TEST_HANG_RANK"] = "0"
+    t0 = time.time()
+    proc = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1"],
+                          capture_output=True, text=True, timeout=300, env=env)
+    assert time.time() - t0 < 120
+    assert proc.returncode != 0 and "rank exit codes [-9, 1]" in proc.stderr
+    assert proc.stdout.strip() == ""
+
+
 def test_grid_size_keeps_the_sphere_inside():
     sys.path.insert(0, ROOT)
     import bench

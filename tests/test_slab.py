@@ -152,6 +152,53 @@ def test_id_indexed_functor_in_slabs_device(device):
 
 
 @pytest.mark.gpu
+def test_rccl_binding_on_one_gpu(device):
+    """A REAL one-rank RCCL communicator through libyalla_hip.so's run-time binding (dlopen, own
+    declarations of the NCCL ABI): ncclGetUniqueId, ncclCommInitRank, ncclAllReduce on device
+    floats and on host doubles, a grouped ncclSend + ncclRecv (to this rank itself) -- every RCCL
+    entry point the N-rank path uses, as far as one GPU can run them."""
+    import ctypes as C
+    lib = slab_mod._core_lib()
+    vp = C.c_void_p
+    lib.ya_comm_unique_id.argtypes = [vp]
+    lib.ya_comm_create.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp)]
+    lib.ya_comm_destroy.argtypes = [vp]
+    lib.ya_comm_allreduce_sum.argtypes = [vp, vp, C.c_int, vp]
+    lib.ya_comm_allreduce_host.argtypes = [vp, C.POINTER(C.c_double), C.c_int, C.c_int]
+    lib.ya_comm_self_exchange.argtypes = [vp, vp, vp, C.c_size_t, vp]
+    lib.ya_malloc.argtypes = [C.POINTER(vp), C.c_size_t]
+    lib.ya_free.argtypes = [vp]
+    lib.ya_memcpy_h2d.argtypes = [vp, vp, C.c_size_t]
+    lib.ya_memcpy_d2h.argtypes = [vp, vp, C.c_size_t]
+    ident = C.create_string_buffer(128)
+    assert lib.ya_comm_unique_id(ident) == 0
+    assert any(ident.raw), "ncclGetUniqueId left the id empty"
+    comm = vp()
+    assert lib.ya_comm_create(ident, 0, 1, C.byref(comm)) == 0
+    n = 1 << 16
+    a = np.random.default_rng(3).random(n).astype(np.float32)
+    d_a, d_b = vp(), vp()
+    assert lib.ya_malloc(C.byref(d_a), a.nbytes) == 0 and lib.ya_malloc(C.byref(d_b), a.nbytes) == 0
+    assert lib.ya_memcpy_h2d(d_a, a.ctypes.data_as(vp), a.nbytes) == 0
+    # sum over one rank = identity
+    assert lib.ya_comm_allreduce_sum(comm, d_a, n, None) == 0
+    back = np.empty_like(a)
+    assert lib.ya_device_synchronize() == 0
+    assert lib.ya_memcpy_d2h(back.ctypes.data_as(vp), d_a, a.nbytes) == 0
+    assert np.array_equal(a, back)
+    # a message to ourselves: the grouped send/recv of ya_comm_exchange
+    assert lib.ya_comm_self_exchange(comm, d_a, d_b, a.nbytes, None) == 0
+    assert lib.ya_device_synchronize() == 0
+    assert lib.ya_memcpy_d2h(back.ctypes.data_as(vp), d_b, a.nbytes) == 0
+    assert np.array_equal(a, back)
+    vals = (C.c_double * 3)(1.5, -2.0, 7.0)
+    assert lib.ya_comm_allreduce_host(comm, vals, 3, 1) == 0 and list(vals) == [1.5, -2.0, 7.0]
+    lib.ya_free(d_a)
+    lib.ya_free(d_b)
+    assert lib.ya_comm_destroy(comm) == 0
+
+
+@pytest.mark.gpu
 def test_rccl_communicator_single_rank(device):
     """ya_comm_* with world_size 1 on the GPU box (RCCL needs one GPU per rank): creation from
     the environment, the host all-reduce, and ya_slab_step driven through ya_slab_use_rccl."""

@@ -140,7 +140,9 @@ int ya_comm_create(const void* id_bytes, int rank, int world, ya_comm** out)
     ya_comm* c = new ya_comm;
     c->rank = rank;
     c->world = world;
-    if (world > 1) {
+    // world 1 with an id: a real one-rank RCCL communicator (tests: the binding exercised on a
+    // one-GPU box); world 1 without: no RCCL at all
+    if (world > 1 || id_bytes) {
         Rccl* r = rccl();
         if (!r || !id_bytes) {
             delete c;
@@ -267,10 +269,23 @@ int ya_comm_exchange(ya_comm* c, const void* d_send_lo, void* d_recv_lo, const v
     return 0;
 }
 
+int ya_comm_self_exchange(ya_comm* c, const void* d_send, void* d_recv, size_t bytes, void* stream)
+{
+    if (!c || !c->comm || !d_send || !d_recv) return (int)hipErrorInvalidValue;
+    Rccl* r = rccl();
+    if (!r) return 999;
+    hipStream_t st = (hipStream_t)stream;
+    YA_RCCL(r->GroupStart(), "ncclGroupStart");
+    YA_RCCL(r->Send(d_send, bytes, NCCL_INT8, c->rank, c->comm, st), "ncclSend (self)");
+    YA_RCCL(r->Recv(d_recv, bytes, NCCL_INT8, c->rank, c->comm, st), "ncclRecv (self)");
+    YA_RCCL(r->GroupEnd(), "ncclGroupEnd");
+    return 0;
+}
+
 int ya_comm_allreduce_sum(ya_comm* c, float* d_buf, int count, void* stream)
 {
     if (!c || !d_buf || count < 0) return (int)hipErrorInvalidValue;
-    if (c->world == 1 || count == 0) return 0;
+    if (!c->comm || count == 0) return 0;
     Rccl* r = rccl();
     if (!r) return 999;
     YA_RCCL(r->AllReduce(d_buf, d_buf, (size_t)count, NCCL_FLOAT32, NCCL_SUM, c->comm, (hipStream_t)stream),
@@ -281,7 +296,7 @@ int ya_comm_allreduce_sum(ya_comm* c, float* d_buf, int count, void* stream)
 int ya_comm_allreduce_host(ya_comm* c, double* values, int count, int take_max)
 {
     if (!c || !values || count < 0 || count > 64) return (int)hipErrorInvalidValue;
-    if (c->world == 1 || count == 0) return 0;
+    if (!c->comm || count == 0) return 0;
     Rccl* r = rccl();
     if (!r) return 999;
     if (hipMemcpy(c->d_bounce, values, (size_t)count * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
