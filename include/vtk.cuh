@@ -6,9 +6,14 @@
 // write_polarity, write_property -- files are output/base_name_#.vtk --
 // and Vtk_input{file_name} with n_points, find_entry, read_positions,
 // read_polarity, read_field, read_property.  This is host code beside the step
-// path (one frame per output interval).  Each section is formatted into one
-// memory buffer and written with a single call instead of one stream insertion
-// per number, which is what dominates wall time at 10^6 cells.
+// path (one frame per output interval) -- but at 10^6 cells it is what a model run spends
+// its wall time on: a frame of positions, polarities and one property is ~7 * 10^6 numbers,
+// seconds of `ostream << float`, against 11 steps of ~3 ms between frames
+// (examples/passive_growth.cu scaled to BASELINE config 4).  So each section is formatted
+// into memory buffers -- numbers by std::to_chars (the digits of "%g", which is what
+// `ostream << float` prints at its default precision of 6; checked against snprintf for
+// 2 * 10^7 values), large sections by several threads over contiguous runs of points -- and
+// written with one call per buffer.  The bytes on disk are the same as before.
 #pragma once
 
 #include <assert.h>
@@ -17,10 +22,12 @@
 #include <sys/stat.h>
 #include <time.h>
 
+#include <charconv>
 #include <fstream>
 #include <iostream>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <typeinfo>
 #include <vector>
 
@@ -56,12 +63,41 @@ public:
         snprintf(&buffer[old_size], (size_t)len + 1, format, args...);
         buffer.resize(old_size + (size_t)len);
     }
+    void add(const char* text) { buffer += text; }  // no arguments: not a format
     void add(const std::string& s) { buffer += s; }
-    // "%g" is what `ostream << float` prints at the default precision of 6
-    void number(float v) { add("%g", (double)v); }
+    void add(char c) { buffer.push_back(c); }
+    // what `ostream << float` prints at the default precision of 6, i.e. "%g"
+    void number(float v)
+    {
+        char piece[32];
+        const auto end = std::to_chars(piece, piece + sizeof(piece), v, std::chars_format::general, 6);
+        buffer.append(piece, end.ptr - piece);
+    }
     void number(double v) { add("%g", v); }
-    void number(int v) { add("%d", v); }
-    void number(unsigned v) { add("%u", v); }
+    void number(int v)
+    {
+        char piece[16];
+        const auto end = std::to_chars(piece, piece + sizeof(piece), v);
+        buffer.append(piece, end.ptr - piece);
+    }
+    void number(unsigned v)
+    {
+        char piece[16];
+        const auto end = std::to_chars(piece, piece + sizeof(piece), v);
+        buffer.append(piece, end.ptr - piece);
+    }
+    // "x y z\n"
+    void row(float x, float y, float z)
+    {
+        number(x);
+        add(' ');
+        number(y);
+        add(' ');
+        number(z);
+        add('\n');
+    }
+    void reserve(size_t bytes) { buffer.reserve(bytes); }
+    const std::string& str() const { return buffer; }
     void write_to(const std::string& path, const char* mode)
     {
         FILE* f = fopen(path.c_str(), mode);
@@ -73,6 +109,43 @@ public:
 private:
     std::string buffer;
 };
+
+// The rows of points [0, n) formatted by `row(i, text)`, in order: one buffer for small n,
+// otherwise one per thread over contiguous runs of points (at most 16 threads, at least
+// 32768 points each).
+template<typename Row>
+std::vector<Text> format_rows(const int n, const Row& row)
+{
+    const int hardware = (int)std::thread::hardware_concurrency();
+    const int threads = std::max(1, std::min({hardware > 0 ? hardware : 1, 16, n / 32768}));
+    std::vector<Text> parts(threads);
+    auto work = [&](const int t) {
+        const long begin = (long)n * t / threads, end = (long)n * (t + 1) / threads;
+        parts[t].reserve((size_t)(end - begin) * 24);
+        for (long i = begin; i < end; i++) row((int)i, parts[t]);
+    };
+    if (threads == 1) {
+        work(0);
+        return parts;
+    }
+    std::vector<std::thread> pool;
+    for (int t = 1; t < threads; t++) pool.emplace_back(work, t);
+    work(0);
+    for (auto& th : pool) th.join();
+    return parts;
+}
+
+// head, then the parts in order, then tail: one fwrite each
+inline void write_sections(const std::string& path, const char* mode, const Text& head,
+    const std::vector<Text>& parts, const Text& tail = Text{})
+{
+    FILE* f = fopen(path.c_str(), mode);
+    assert(f != NULL);
+    fwrite(head.str().data(), 1, head.str().size(), f);
+    for (const auto& part : parts) fwrite(part.str().data(), 1, part.str().size(), f);
+    fwrite(tail.str().data(), 1, tail.str().size(), f);
+    fclose(f);
+}
 }  // namespace ya
 
 
@@ -138,14 +211,18 @@ public:
         out.add(base_name + "\n");
         out.add("ASCII\nDATASET POLYDATA\n");
         out.add("\nPOINTS %d float\n", n_to_write);
-        for (int i = 0; i < n_points; i++) {
-            if (skipped(i)) continue;
-            out.add("%g %g %g\n", (double)points.h_X[i].x, (double)points.h_X[i].y,
-                (double)points.h_X[i].z);
-        }
-        out.add("\nVERTICES %d %d\n", n_to_write, 2 * n_to_write);
-        for (int i = 0; i < n_to_write; i++) out.add("1 %d\n", i);
-        out.write_to(current_path, "w");
+        const auto* X = points.h_X;
+        ya::write_sections(current_path, "w", out, ya::format_rows(n_points, [&](int i, ya::Text& t) {
+            if (!skipped(i)) t.row(X[i].x, X[i].y, X[i].z);
+        }));
+        ya::Text vertices;
+        vertices.add("\nVERTICES %d %d\n", n_to_write, 2 * n_to_write);
+        ya::write_sections(current_path, "a", vertices, ya::format_rows(n_to_write, [](int i, ya::Text& t) {
+            t.add('1');
+            t.add(' ');
+            t.number(i);
+            t.add('\n');
+        }));
 
         point_data_started = false;
         time_step += 1;
@@ -161,9 +238,15 @@ public:
     {
         ya::Text out;
         out.add("\nLINES %d %d\n", *links.h_n, 3 * *links.h_n);
-        for (int i = 0; i < *links.h_n; i++)
-            out.add("2 %d %d\n", links.h_link[i].a, links.h_link[i].b);
-        out.write_to(current_path, "a");
+        const Link* link = links.h_link;
+        ya::write_sections(current_path, "a", out, ya::format_rows(*links.h_n, [&](int i, ya::Text& t) {
+            t.add('2');
+            t.add(' ');
+            t.number(link[i].a);
+            t.add(' ');
+            t.number(link[i].b);
+            t.add('\n');
+        }));
     }
 
     // Write further components of Pt
@@ -174,11 +257,12 @@ public:
         ya::Text out;
         start_point_data(out);
         out.add("SCALARS %s float\nLOOKUP_TABLE default\n", data_name);
-        for (int i = 0; i < n_points; i++) {
-            if (skipped(i)) continue;
-            out.add("%g\n", (double)(points.h_X[i].*field));
-        }
-        out.write_to(current_path, "a");
+        const auto* X = points.h_X;
+        ya::write_sections(current_path, "a", out, ya::format_rows(n_points, [&](int i, ya::Text& t) {
+            if (skipped(i)) return;
+            t.number(X[i].*field);
+            t.add('\n');
+        }));
     }
 
     // Write a polarity vector of Pt (theta and phi by default, see polarity.cuh).
@@ -190,13 +274,13 @@ public:
         ya::Text out;
         start_point_data(out);
         out.add("NORMALS %s float\n", data_name);
-        for (int i = 0; i < n_points; i++) {
-            if (skipped(i)) continue;
-            float3 n = pol_to_float3<Pt, theta, phi>(points.h_X[i]);
-            if ((points.h_X[i].*theta == 0) and (points.h_X[i].*phi == 0)) n.z = 0;
-            out.add("%g %g %g\n", (double)n.x, (double)n.y, (double)n.z);
-        }
-        out.write_to(current_path, "a");
+        const auto* X = points.h_X;
+        ya::write_sections(current_path, "a", out, ya::format_rows(n_points, [&](int i, ya::Text& t) {
+            if (skipped(i)) return;
+            float3 n = pol_to_float3<Pt, theta, phi>(X[i]);
+            if ((X[i].*theta == 0) and (X[i].*phi == 0)) n.z = 0;
+            t.row(n.x, n.y, n.z);
+        }));
     }
 
     // Write not integrated property, see property.cuh
@@ -208,12 +292,12 @@ public:
         start_point_data(out);
         const char* ptype = typeid(Prop) == typeid(float) ? "float" : "int";
         out.add("SCALARS " + property.name + " " + ptype + "\nLOOKUP_TABLE default\n");
-        for (int i = 0; i < n_points; i++) {
-            if (skipped(i)) continue;
-            out.number(property.h_prop[i]);
-            out.add("\n");
-        }
-        out.write_to(current_path, "a");
+        const Prop* prop = property.h_prop;
+        ya::write_sections(current_path, "a", out, ya::format_rows(n_points, [&](int i, ya::Text& t) {
+            if (skipped(i)) return;
+            t.number(prop[i]);
+            t.add('\n');
+        }));
     }
 };
 

@@ -46,3 +46,10 @@ def test_header_level_slab_solver():
     from the environment, slab_init / slab_setup / slab_use_rccl, take_step; an id-indexed functor
     with local index != global id; the callback transport.  One rank (one GPU per box)."""
     run("test_slab_solver", "ALL SLAB SOLVER TESTS PASSED")
+
+
+@pytest.mark.gpu
+def test_vtk_output_at_a_million_cells():
+    """Vtk_output (include/vtk.cuh) at config 4's size: byte for byte what one stream insertion
+    per number writes (with and without a mask), faster than that, read back by Vtk_input."""
+    run("test_vtk_speed", "ALL VTK SPEED TESTS PASSED")
