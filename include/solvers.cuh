@@ -1586,13 +1586,21 @@ public:
     {
         *h_n = n_max;
         h_X = (Pt*)calloc(n_max, sizeof(Pt));
+        // page-locked: a frame's copy_to_host moves all n_max points (26 MB at config 4)
+        h_X_locked = n_max > 0 && ya_host_register(h_X, (size_t)n_max * sizeof(Pt)) == 0;
     }
     ~Solution()
     {
+        if (h_X_locked) (void)ya_host_unregister(h_X);
         free(h_X);
         free(h_n);
     }
     Solution(const Solution&) = delete;
+
+private:
+    bool h_X_locked = false;
+
+public:
     void copy_to_device()
     {
         assert(*h_n <= n_max);

@@ -29,7 +29,7 @@ extern "C" {
 /* The libraries are built with -fvisibility=hidden; only this C ABI is exported. */
 #pragma GCC visibility push(default)
 
-#define YA_ABI_VERSION 5
+#define YA_ABI_VERSION 6
 
 /* Status bits reported by ya_grid_status(). */
 #define YA_STATUS_OUT_OF_GRID 1 /* a cell's cube id fell outside [0, n_cubes):
@@ -46,6 +46,12 @@ int ya_free(void* d_ptr);
 int ya_memset_async(void* d_ptr, int value, size_t bytes, void* stream);
 int ya_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes);
 int ya_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes);
+/* Page-locks (and releases) a host array the caller allocated, so that the copies of a
+ * Solution's host mirror (copy_to_host / copy_to_device, reference solvers.cuh:92-104: the whole
+ * n_max points per output frame) run at PCIe speed instead of through a staging buffer.
+ * Failure to lock is not an error of the model: the array stays usable, the copies slower. */
+int ya_host_register(void* h_ptr, size_t bytes);
+int ya_host_unregister(void* h_ptr);
 int ya_memcpy_d2d_async(void* d_dst, const void* d_src, size_t bytes, void* stream);
 int ya_device_synchronize(void);
 

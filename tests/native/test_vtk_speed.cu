@@ -91,6 +91,15 @@ int main()
     for (int i = 0; i < n; i++) keep[i] = (rng() % 4) != 0;
     bool* mask = reinterpret_cast<bool*>(keep.data());
 
+    {  // the other half of an output frame: the host mirror's trip over PCIe (page-locked)
+        cells.copy_to_device();
+        auto t0 = std::chrono::steady_clock::now();
+        for (int k = 0; k < 10; k++) cells.copy_to_host();
+        const double each = seconds_since(t0) / 10;
+        printf("copy_to_host of %d Po_cell cells (%.0f MB): %.2f ms = %.1f GB/s\n", n, n * 20 / 1e6, each * 1e3,
+            n * 20 / each / 1e9);
+        EXPECT(cells.h_X[12345].x != 0.f && *cells.h_n == n);
+    }
     const std::string dir = "/tmp/yalla_vtk_speed/";
     {
         Vtk_output out{"fast", dir, false};
