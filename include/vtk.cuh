@@ -17,8 +17,10 @@
 #pragma once
 
 #include <assert.h>
+#include <ctype.h>
 #include <math.h>
 #include <stdio.h>
+#include <string.h>
 #include <sys/stat.h>
 #include <time.h>
 
@@ -304,13 +306,76 @@ public:
 
 class Vtk_input {
     std::string file_name;
+    std::string text;  // the whole file: sections are located and parsed in memory
 
-    // Stream positioned on the first data line of the section "key1 key2 ...".
-    void open_at(std::ifstream& in, std::string keyword1, std::string keyword2)
+    // (Re)load the file if it is not the size held in memory: sections may be appended to a
+    // file after this object was made (the reference opens the file anew for every read,
+    // and its tests/test_vtk.cu:56-59 relies on that).
+    void load()
     {
-        in.open(file_name);
+        struct stat info;
+        const bool there = stat(file_name.c_str(), &info) == 0;
+        assert(there and "vtk file not found");
+        if (!there or (size_t)info.st_size == text.size()) return;
+        std::ifstream in(file_name, std::ios::binary);
         assert(in.is_open());
-        in.seekg(find_entry(keyword1, keyword2));
+        text.resize((size_t)info.st_size);
+        in.read(&text[0], (std::streamsize)text.size());
+    }
+
+    // First character after the line starting with the two keywords (header skipped)
+    size_t entry_offset(const std::string& keyword1, const std::string& keyword2)
+    {
+        load();
+        const char *p = text.data(), *end = p + text.size();
+        for (int i = 0; i < 4 and p < end; i++) {  // header: avoid false matches
+            const char* nl = (const char*)memchr(p, '\n', end - p);
+            p = nl ? nl + 1 : end;
+        }
+        while (p < end) {
+            const char* nl = (const char*)memchr(p, '\n', end - p);
+            const char* line_end = nl ? nl : end;
+            // the first two whitespace-separated items of the line
+            const char* q = p;
+            while (q < line_end and isspace((unsigned char)*q)) q++;
+            const char* a = q;
+            while (q < line_end and !isspace((unsigned char)*q)) q++;
+            const size_t a_len = q - a;
+            while (q < line_end and isspace((unsigned char)*q)) q++;
+            const char* b = q;
+            while (q < line_end and !isspace((unsigned char)*q)) q++;
+            const size_t b_len = q - b;
+            if (b_len > 0 and a_len == keyword1.size() and b_len == keyword2.size() and
+                memcmp(a, keyword1.data(), a_len) == 0 and memcmp(b, keyword2.data(), b_len) == 0)
+                return (nl ? nl + 1 : end) - text.data();
+            p = nl ? nl + 1 : end;
+        }
+        assert(false and "entry not found in vtk file");
+        return text.size();
+    }
+    const char* skip_line(const char* p) const
+    {
+        const char* end = text.data() + text.size();
+        const char* nl = (const char*)memchr(p, '\n', end - p);
+        return nl ? nl + 1 : end;
+    }
+    // the next whitespace-separated number, as `istream >> value` reads it
+    template<typename T>
+    const char* parse(const char* p, T& value) const
+    {
+        const char* end = text.data() + text.size();
+        while (p < end and isspace((unsigned char)*p)) p++;
+        if (p < end and *p == '+') p++;
+        const auto result = std::from_chars(p, end, value);
+        assert(result.ec == std::errc() and "number expected in vtk file");
+        return result.ptr;
+    }
+    const char* parse(const char* p, bool& value) const
+    {
+        int v = 0;
+        p = parse(p, v);
+        value = v != 0;
+        return p;
     }
 
 public:
@@ -318,11 +383,11 @@ public:
 
     Vtk_input(std::string file_name) : file_name{file_name}
     {
-        std::ifstream in(file_name);
-        assert(in.is_open());
-        std::string line;
+        load();
         n_points = 0;
-        for (int i = 0; i < 6 and getline(in, line); i++) {
+        std::istringstream head(text.substr(0, std::min<size_t>(text.size(), 4096)));
+        std::string line;
+        for (int i = 0; i < 6 and getline(head, line); i++) {
             const auto items = split(line);
             if (items.size() > 1 and items[0] == "POINTS") {
                 n_points = stoi(items[1]);
@@ -334,36 +399,32 @@ public:
     // Position after the line starting with the two keywords (header skipped)
     std::streampos find_entry(std::string keyword1, std::string keyword2)
     {
-        std::ifstream in(file_name);
-        assert(in.is_open());
-        std::string line;
-        for (int i = 0; i < 4; i++) getline(in, line);  // header: avoid false matches
-        while (getline(in, line)) {
-            const auto items = split(line);
-            if (items.size() > 1 and items[0] == keyword1 and items[1] == keyword2)
-                return in.tellg();
-        }
-        assert(false and "entry not found in vtk file");
-        return in.tellg();
+        return (std::streampos)entry_offset(keyword1, keyword2);
     }
 
     template<typename Pt, template<typename> class Solver>
     void read_positions(Solution<Pt, Solver>& points)
     {
-        std::ifstream in;
-        open_at(in, "POINTS", std::to_string(n_points));
-        for (int i = 0; i < n_points; i++) in >> points.h_X[i].x >> points.h_X[i].y >> points.h_X[i].z;
+        const size_t at = entry_offset("POINTS", std::to_string(n_points));  // may reload `text`
+        const char* p = text.data() + at;
+        for (int i = 0; i < n_points; i++) {
+            p = parse(p, points.h_X[i].x);
+            p = parse(p, points.h_X[i].y);
+            p = parse(p, points.h_X[i].z);
+        }
     }
 
     // Read polarity of Pt, see polarity.cuh (the normals are unit vectors)
     template<typename Pt, template<typename> class Solver>
     void read_polarity(Solution<Pt, Solver>& points)
     {
-        std::ifstream in;
-        open_at(in, "NORMALS", "polarity");
+        const size_t at = entry_offset("NORMALS", "polarity");
+        const char* p = text.data() + at;
         for (int i = 0; i < n_points; i++) {
             float x, y, z;
-            in >> x >> y >> z;
+            p = parse(p, x);
+            p = parse(p, y);
+            p = parse(p, z);
             if (x == 0 and y == 0 and z == 0) {
                 points.h_X[i].phi = 0.0f;
                 points.h_X[i].theta = 0.0f;
@@ -379,11 +440,9 @@ public:
     void read_field(
         Solution<Pt, Solver>& points, const char* data_name = "w", float Pt::*field = &Pt::w)
     {
-        std::ifstream in;
-        open_at(in, "SCALARS", data_name);
-        std::string line;
-        getline(in, line);  // LOOKUP_TABLE line
-        for (int i = 0; i < n_points; i++) in >> points.h_X[i].*field;
+        const size_t at = entry_offset("SCALARS", data_name);
+        const char* p = skip_line(text.data() + at);  // LOOKUP_TABLE line
+        for (int i = 0; i < n_points; i++) p = parse(p, points.h_X[i].*field);
     }
 
     // Read property, see property.cuh
@@ -391,10 +450,8 @@ public:
     void read_property(Property<Prop>& property, std::string prop_name)
     {
         assert(n_points <= property.n_max);
-        std::ifstream in;
-        open_at(in, "SCALARS", prop_name);
-        std::string line;
-        getline(in, line);  // LOOKUP_TABLE line
-        for (int i = 0; i < n_points; i++) in >> property.h_prop[i];
+        const size_t at = entry_offset("SCALARS", prop_name);
+        const char* p = skip_line(text.data() + at);  // LOOKUP_TABLE line
+        for (int i = 0; i < n_points; i++) p = parse(p, property.h_prop[i]);
     }
 };

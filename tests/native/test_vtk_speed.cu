@@ -124,12 +124,19 @@ int main()
         EXPECT(slurp(dir + "fast_1.vtk") == slurp(dir + "streams_1.vtk"));
     }
     {  // and back: Vtk_input reads what was written (6 significant digits)
+        auto t0 = std::chrono::steady_clock::now();
         Vtk_input in{dir + "fast_0.vtk"};
         EXPECT(in.n_points == n);
         Solution<Po_cell, Tile_solver> back{n};
         *back.h_n = n;
         in.read_positions(back);
         in.read_polarity(back);
+        Property<int> type_back{n, "type"};
+        in.read_property(type_back, "type");
+        printf("Vtk_input of the same frame: %.3f s\n", seconds_since(t0));
+        int wrong = 0;
+        for (int i = 0; i < n; i++) wrong += type_back.h_prop[i] != type.h_prop[i];
+        EXPECT(wrong == 0);
         double worst = 0;
         for (int i = 0; i < n; i += 97)
             worst = std::max(worst, (double)std::fabs(back.h_X[i].y - cells.h_X[i].y) /
