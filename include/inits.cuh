@@ -122,6 +122,41 @@ __device__ Pt relu_force(Pt Xi, Pt r, float dist, int i, int j)
 }
 
 namespace ya {
+// While one of these lives, a solver that has cooperative force kernels uses them (several lanes
+// per cell: Tile_computer::lanes_per_cell = 64, Grid_computer::force_variant = 3; bit-identical
+// results).  For steps whose functor is known to keep no per-cell state, like relu_force here.
+template<typename S>
+class Cooperative_kernels {
+    S& solver;
+    int saved_lanes = 0, saved_variant = 0;
+    template<typename T>
+    static auto lanes(T& s, int) -> decltype(s.lanes_per_cell)* { return &s.lanes_per_cell; }
+    template<typename T>
+    static int* lanes(T&, long) { return nullptr; }
+    template<typename T>
+    static auto variant(T& s, int) -> decltype(s.force_variant)* { return &s.force_variant; }
+    template<typename T>
+    static int* variant(T&, long) { return nullptr; }
+
+public:
+    explicit Cooperative_kernels(S& s) : solver{s}
+    {
+        if (int* l = lanes(solver, 0)) {
+            saved_lanes = *l;
+            if (*l == 1) *l = 64;
+        }
+        if (int* v = variant(solver, 0)) {
+            saved_variant = *v;
+            if (*v == 2) *v = 3;
+        }
+    }
+    ~Cooperative_kernels()
+    {
+        if (int* l = lanes(solver, 0)) *l = saved_lanes;
+        if (int* v = variant(solver, 0)) *v = saved_variant;
+    }
+};
+
 template<typename Pt, template<typename> class Solver>
 void relax_and_rescale(
     double scale, Solution<Pt, Solver>& points, int steps, int warn_above)
@@ -129,7 +164,11 @@ void relax_and_rescale(
     if (*points.h_n > warn_above)
         std::cout << "Warning: The system is quite large, it may "
                   << "not be completely relaxed." << std::endl;
-    for (int i = 0; i < steps; i++) points.template take_step<relu_force>(0.1f);
+    {
+        // 500-3000 steps of a few hundred to a few thousand cells: model set-up time is these
+        Cooperative_kernels<Solution<Pt, Solver>> several_lanes_per_cell{points};
+        for (int i = 0; i < steps; i++) points.template take_step<relu_force>(0.1f);
+    }
     points.copy_to_host();
     for (int i = 0; i < *points.h_n; i++) {
         points.h_X[i].x *= scale;

@@ -4,8 +4,10 @@
 #include "../../include/inits.cuh"
 #include "../../include/solvers.cuh"
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <vector>
 
 static int failures = 0;
@@ -94,6 +96,48 @@ int main()
             EXPECT(c.h_X[i].z >= 2.f && c.h_X[i].z <= 4.f);
         }
         EXPECT(c.get_d_n() == expected);  // and the device knows
+    }
+    {  // relaxed_sphere / relaxed_cuboid (reference inits.cuh:95-155) relax with the cooperative
+       // kernels (several lanes per cell; relu_force keeps no per-cell state): the result must be
+       // bit for bit what one lane per cell gives, and nearest neighbours end at dist_to_nb
+        for (int grid = 0; grid < 2; grid++) {
+            const int n = grid ? 4000 : 800;
+            std::vector<float3> results[2];
+            double seconds[2];
+            for (int coop = 0; coop < 2; coop++) {
+                auto run = [&](auto& p) {
+                    const auto t0 = std::chrono::steady_clock::now();
+                    if (coop) {
+                        relaxed_sphere(0.75f, p, 0, 11);
+                    } else {  // the same steps on the default kernels
+                        random_sphere(0.6f, p, 0, 11);
+                        for (int i = 0; i < (n <= 1000 ? 1000 : 2000); i++) p.template take_step<relu_force>(0.1f);
+                        p.copy_to_host();
+                        for (int i = 0; i < n; i++) {
+                            p.h_X[i].x *= 0.75 / 0.8;
+                            p.h_X[i].y *= 0.75 / 0.8;
+                            p.h_X[i].z *= 0.75 / 0.8;
+                        }
+                    }
+                    seconds[coop] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                    results[coop].assign(p.h_X, p.h_X + n);
+                };
+                if (grid) {
+                    Solution<float3, Grid_solver> p{n, 50, 1.f};
+                    run(p);
+                    EXPECT(p.force_variant == 2);  // restored
+                } else {
+                    Solution<float3, Tile_solver> p{n};
+                    run(p);
+                    EXPECT(p.lanes_per_cell == 1);
+                }
+            }
+            int different = 0;
+            for (int i = 0; i < n; i++) different += memcmp(&results[0][i], &results[1][i], sizeof(float3)) != 0;
+            EXPECT(different == 0);
+            printf("relaxed_sphere, %d cells, %s: %.3f s (one lane per cell: %.3f s)\n", n,
+                grid ? "Grid_solver" : "Tile_solver", seconds[1], seconds[0]);
+        }
     }
     printf(failures ? "%d FAILURES\n" : "ALL SHAPE TESTS PASSED\n", failures);
     return failures != 0;
