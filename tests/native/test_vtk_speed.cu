@@ -13,7 +13,9 @@
 #include <fstream>
 #include <random>
 #include <sstream>
+#include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 static int failures = 0;
@@ -142,6 +144,36 @@ int main()
             worst = std::max(worst, (double)std::fabs(back.h_X[i].y - cells.h_X[i].y) /
                                         std::max(1e-3, (double)std::fabs(cells.h_X[i].y)));
         EXPECT(worst < 1e-5);
+    }
+    {  // a model's output loop (reference examples/branching.cu:263-280): the steps of the next
+       // frame run in a worker thread while the main thread writes the frame it copied to the host
+       // -- take_step must touch neither h_X nor h_n, and must work from any host thread
+        const int m = 60000;
+        auto simulate = [&](bool threaded, std::vector<float3>& final_state, std::string& frame) {
+            Solution<float3, Grid_solver> s{m, 64, 1.f};
+            random_sphere(0.5f, s, 0, 3);
+            Vtk_output out{threaded ? "threaded" : "serial", dir, false};
+            for (int f = 0; f < 3; f++) {
+                s.copy_to_host();
+                if (threaded) {
+                    std::thread worker([&] { for (int k = 0; k < 5; k++) s.take_step<relu_force>(0.05f); });
+                    out.write_positions(s);
+                    worker.join();
+                } else {
+                    out.write_positions(s);
+                    for (int k = 0; k < 5; k++) s.take_step<relu_force>(0.05f);
+                }
+            }
+            s.copy_to_host();
+            final_state.assign(s.h_X, s.h_X + m);
+            frame = slurp(dir + (threaded ? "threaded_2.vtk" : "serial_2.vtk"));
+        };
+        std::vector<float3> a, b;
+        std::string frame_a, frame_b;
+        simulate(false, a, frame_a);
+        simulate(true, b, frame_b);
+        EXPECT(memcmp(a.data(), b.data(), m * sizeof(float3)) == 0);
+        EXPECT(frame_a.size() > 1000000u && frame_a.substr(frame_a.find("ASCII")) == frame_b.substr(frame_b.find("ASCII")));
     }
     if (failures == 0) printf("ALL VTK SPEED TESTS PASSED\n");
     return failures != 0;

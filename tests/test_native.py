@@ -51,5 +51,7 @@ def test_header_level_slab_solver():
 @pytest.mark.gpu
 def test_vtk_output_at_a_million_cells():
     """Vtk_output (include/vtk.cuh) at config 4's size: byte for byte what one stream insertion
-    per number writes (with and without a mask), faster than that, read back by Vtk_input."""
+    per number writes (with and without a mask), faster than that, read back by Vtk_input; and a
+    model's output loop with the steps in a worker thread (examples/branching.cu:263-280): same
+    frames, same final state as the serial loop."""
     run("test_vtk_speed", "ALL VTK SPEED TESTS PASSED")
