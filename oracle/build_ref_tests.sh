@@ -8,6 +8,8 @@
 #   test_dtypes test_solvers test_links test_inits test_vtk   -> built
 #   test_polarity  stale in the reference itself   -> skipped
 #   test_mesh      needs mesh.cuh (out of scope)               -> skipped
+# and the model programs of the four BASELINE configurations (examples/springs.cu, sorting.cu,
+# passive_growth.cu, branching.cu; unmodified too) into oracle/_ref/examples/.
 set -e
 REF=${REF:-/root/reference}
 HERE=$(cd "$(dirname "$0")" && pwd)
@@ -25,4 +27,13 @@ for t in test_dtypes test_solvers test_links test_inits test_vtk; do
       -Wno-error=parentheses -w -include "$ROOT/include/compat/cuda_names.h" -I"$ROOT/include/compat" \
       $t.cu -L"$ROOT/yalla_amd" -lyalla_hip -Wl,-rpath,'$ORIGIN/../../yalla_amd' -o "$OUT/$t"
   echo "built oracle/_ref/$t"
+done
+mkdir -p "$OUT/examples" "$TREE/examples"
+for f in "$REF"/examples/*; do ln -s "$f" "$TREE/examples/"; done
+cd "$TREE/examples"
+for m in springs sorting passive_growth branching; do
+  /opt/rocm/bin/hipcc -x hip --offload-arch=gfx950 -std=c++17 -O2 -ffp-contract=off -fno-slp-vectorize \
+      -Wno-error=parentheses -w -include "$ROOT/include/compat/cuda_names.h" -I"$ROOT/include/compat" \
+      $m.cu -L"$ROOT/yalla_amd" -lyalla_hip -lpthread -Wl,-rpath,'$ORIGIN/../../../yalla_amd' -o "$OUT/examples/$m"
+  echo "built oracle/_ref/examples/$m"
 done
