@@ -16,13 +16,14 @@ BIN = os.path.join(ROOT, "oracle", "_ref", "examples")
 pytestmark = pytest.mark.gpu
 
 
-def run_model(name, tmp_path, seed=1):
+def run_model(name, tmp_path, seed=1, may_end_with=None):
     exe = os.path.join(BIN, name)
     if not os.path.exists(exe):
         pytest.skip(f"{exe} was not built (no reference checkout here)")
     env = dict(os.environ, YALLA_SEED=str(seed))  # pins random_sphere & co. (include/inits.cuh)
     proc = subprocess.run([exe], cwd=tmp_path, capture_output=True, text=True, timeout=900, env=env)
-    assert proc.returncode == 0, proc.stdout[-1500:] + proc.stderr[-1500:]
+    if not (may_end_with and proc.returncode != 0 and may_end_with in proc.stderr):
+        assert proc.returncode == 0, proc.stdout[-1500:] + proc.stderr[-1500:]
     return sorted(os.listdir(tmp_path / "output"))
 
 
@@ -93,10 +94,32 @@ def test_passive_growth(tmp_path):
 def test_branching(tmp_path):
     """examples/branching.cu (config 3's program): 500 cells grow by two orders of magnitude in
     501 frames, steps in a worker thread while the main thread writes, then the lineage tree."""
-    frames = run_model("branching", tmp_path)
+    # Proliferation is seeded with time(NULL) (branching.cu:205-207).  When a run's 2.5e5 cells and
+    # their ~2.5e5 tree nodes together exceed the model's own n_max = 500000, its final lineage-tree
+    # output trips the assert the reference's Vtk_output has as well (vtk.cuh:207) -- the model's
+    # limit, after all 501 frames of the simulation are written.
+    frames = run_model("branching", tmp_path, may_end_with="n_points <= property.n_max")
     model = [f for f in frames if ".tree" not in f]
-    assert len(model) == 501 and len(frames) == 502
+    assert len(model) == 501 and len(frames) in (501, 502)
     last = read_frame(tmp_path / "output" / sorted(model, key=lambda f: int(f.rsplit("_", 1)[1][:-4]))[-1])
     assert len(last["points"]) > 50_000 and np.isfinite(last["points"]).all()
     assert np.isfinite(last["u"]).all() and np.isfinite(last["v"]).all()
     assert (last["u"] != 0).sum() > 1000   # the Turing fields live on the epithelium
+
+
+OTHER_MODELS = ["apical_constriction", "bending", "epithelia_double_polarity", "epithelium", "gradient",
+                "growth_w_wall", "intercalation", "lineage_tracing", "migration", "random_walk",
+                "sorting_prot", "turing", "turing_w_noise", "wnt", "write_vtk_w_mask"]
+
+
+@pytest.mark.parametrize("name", OTHER_MODELS)
+def test_other_example_programs_run(tmp_path, name):
+    """The other 15 reference examples that compile (polarity models, Gabriel solver + walls,
+    links / protrusions, lineage tracing, Turing patterns with noise, masks): each runs to
+    completion and its last frame holds finite positions."""
+    frames = run_model(name, tmp_path)
+    assert len(frames) >= 1
+    numbered = sorted((f for f in frames if f.endswith(".vtk")),
+                      key=lambda f: (f.rsplit("_", 1)[0], int(f.rsplit("_", 1)[1][:-4])))
+    last = read_frame(tmp_path / "output" / numbered[-1])
+    assert len(last["points"]) > 0 and np.isfinite(last["points"]).all()
