@@ -347,11 +347,14 @@ def test_graph_replay_is_the_same_step(oracle, device):
     for model, n, dts in (("springs_grid", 20000, (0.001, 0.001, 0.001, 0.001, 0.002, 0.002, 0.002)),
                           ("relu_po_grid", 6000, (0.05,) * 6)):
         res = []
-        for mode in ("oracle", 0, 1, -1):
+        for mode in ("oracle", 0, 1, -1, "coop"):   # "coop": the replayed step with several lanes per cell
             lib = oracle if mode == "oracle" else device
             with Solution(model, n, 50, 1.0, lib=lib) as s:
                 if mode == "oracle":
                     s.set_reduce_order(1)
+                elif mode == "coop":
+                    s.set_param("graph", 1)
+                    s.set_param("force_variant", 3)
                 else:
                     s.set_param("graph", mode)
                 s.random_sphere(0.5, 9)
