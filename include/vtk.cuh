@@ -24,6 +24,7 @@
 #include <sys/stat.h>
 #include <time.h>
 
+#include <algorithm>
 #include <charconv>
 #include <fstream>
 #include <iostream>
