@@ -1103,10 +1103,13 @@ namespace coop {
 constexpr int BLOCK = 256;
 constexpr int MAX_HITS = 96;  // hit-list length per cell; more hits are worked off in parts
 constexpr int STRETCH = 64;   // candidates of a row ranked at a time (<= MAX_HITS, <= 32 per lane)
-// staged cells: nine rows of (the workgroup's cells + two cubes) at rho ~ 10 per cube
+// staged cells: nine rows of (the workgroup's cells + two cubes) at rho ~ 10 per cube; wider
+// entries go plane by plane unless the workgroup is 16 cells (branching model, 32-byte entries,
+// 10^4 cells: 200 -> 171 us per step with all rows at once, but 3 * 10^4 with 8 lanes 212 -> 225)
 template<typename Pt, int LANES>
 struct Stage {
-    static constexpr int value = (sizeof(Entry<Pt>) <= 16 ? 9 : 5) * (BLOCK / LANES + 34);
+    static constexpr bool all_rows = sizeof(Entry<Pt>) <= 16 || (sizeof(Entry<Pt>) <= 32 && LANES == 16);
+    static constexpr int value = (all_rows ? 9 : 5) * (BLOCK / LANES + 34);
 };
 // Lanes per cell for a launch of n cells (MI355X, springs at rho ~ 10, tools/micro/force_ab.hip:
 // 16 lanes 19 us at 10^4 cells, 8 lanes 24 us at 3 * 10^4, 4 lanes 55 us at 10^5, where one lane
