@@ -41,6 +41,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <functional>
 #include <utility>
@@ -1588,14 +1589,21 @@ public:
     Solution(int n_max, Args... args) : Solver<Pt>{n_max, args...}, n_max{n_max}
     {
         *h_n = n_max;
-        h_X = (Pt*)calloc(n_max, sizeof(Pt));
-        // page-locked: a frame's copy_to_host moves all n_max points (26 MB at config 4)
-        h_X_locked = n_max > 0 && ya_host_register(h_X, (size_t)n_max * sizeof(Pt)) == 0;
+        // page-locked if the runtime grants it: a frame's copy_to_host moves all n_max points
+        // (26 MB at config 4); zeroed like calloc'ed memory
+        const size_t bytes = (size_t)n_max * sizeof(Pt);
+        h_X_locked = n_max > 0 && ya_host_alloc((void**)&h_X, bytes) == 0;
+        if (h_X_locked)
+            memset((void*)h_X, 0, bytes);
+        else
+            h_X = (Pt*)calloc(n_max, sizeof(Pt));
     }
     ~Solution()
     {
-        if (h_X_locked) (void)ya_host_unregister(h_X);
-        free(h_X);
+        if (h_X_locked)
+            (void)ya_host_free(h_X);
+        else
+            free(h_X);
         free(h_n);
     }
     Solution(const Solution&) = delete;

@@ -46,12 +46,14 @@ int ya_free(void* d_ptr);
 int ya_memset_async(void* d_ptr, int value, size_t bytes, void* stream);
 int ya_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes);
 int ya_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes);
-/* Page-locks (and releases) a host array the caller allocated, so that the copies of a
- * Solution's host mirror (copy_to_host / copy_to_device, reference solvers.cuh:92-104: the whole
- * n_max points per output frame) run at PCIe speed instead of through a staging buffer.
- * Failure to lock is not an error of the model: the array stays usable, the copies slower. */
-int ya_host_register(void* h_ptr, size_t bytes);
-int ya_host_unregister(void* h_ptr);
+/* Page-locked host memory (hipHostMalloc / hipHostFree) for a Solution's host mirror, so that
+ * copy_to_host / copy_to_device (reference solvers.cuh:92-104: the whole n_max points per output
+ * frame) run at PCIe speed instead of through a staging buffer.  The reference's h_X is pageable
+ * malloc memory; models only index it.  (Page-locking malloc'ed memory in place, hipHostRegister,
+ * was tried first: after some hundred register / unregister cycles of small arrays a later kernel
+ * faulted -- tests/fuzz_parity.py found it.) */
+int ya_host_alloc(void** h_ptr, size_t bytes);
+int ya_host_free(void* h_ptr);
 int ya_memcpy_d2d_async(void* d_dst, const void* d_src, size_t bytes, void* stream);
 int ya_device_synchronize(void);
 

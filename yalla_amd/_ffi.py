@@ -70,7 +70,7 @@ MODELS_ABI = {
 # include/yalla_hip.h, for the export check (no compute calls without a GPU).
 CORE_ABI = [
     "ya_abi_version", "ya_malloc", "ya_free", "ya_memset_async", "ya_memcpy_h2d",
-    "ya_memcpy_d2h", "ya_host_register", "ya_host_unregister", "ya_memcpy_d2d_async", "ya_device_synchronize", "ya_get_n",
+    "ya_memcpy_d2h", "ya_host_alloc", "ya_host_free", "ya_memcpy_d2d_async", "ya_device_synchronize", "ya_get_n",
     "ya_grid_create", "ya_grid_destroy", "ya_grid_arrays", "ya_grid_offsets",
     "ya_grid_build", "ya_grid_build_sorted", "ya_grid_build_sorted_begin",
     "ya_grid_build_sorted_finish", "ya_grid_rebuild_sorted", "ya_n_reader_create", "ya_n_reader_destroy",

@@ -488,12 +488,12 @@ int ya_memcpy_d2h(void* h, const void* d, size_t bytes)
 {
     return (int)hipMemcpy(h, d, bytes, hipMemcpyDeviceToHost);
 }
-int ya_host_register(void* h, size_t bytes)
+int ya_host_alloc(void** h, size_t bytes)
 {
-    if (!h || bytes == 0) return (int)hipErrorInvalidValue;
-    return (int)hipHostRegister(h, bytes, hipHostRegisterDefault);
+    if (!h) return (int)hipErrorInvalidValue;
+    return (int)hipHostMalloc(h, bytes ? bytes : 4, hipHostMallocDefault);
 }
-int ya_host_unregister(void* h) { return h ? (int)hipHostUnregister(h) : (int)hipErrorInvalidValue; }
+int ya_host_free(void* h) { return h ? (int)hipHostFree(h) : 0; }
 int ya_memcpy_d2d_async(void* dst, const void* src, size_t bytes, void* stream)
 {
     return (int)hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream);
