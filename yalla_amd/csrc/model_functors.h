@@ -325,26 +325,40 @@ __global__ void k_mothers(float rate, unsigned seed, unsigned step, int n,
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) flag[i] = Rule::divides(rate, seed, step, i, n, X, type, mes_nbs, epi_nbs);
 }
-// exclusive prefix of the flags by ONE workgroup (model-side helper, not a hot path)
-__global__ __launch_bounds__(1024) void k_daughter_slots(int n, int* flag_to_offset, int* d_n, int n_max)
+// Exclusive prefix of the mothers' flags = the daughters' slots behind the n existing cells, in
+// the order of the mothers' ids (the oracle's loop order): block sums, their prefix by one
+// workgroup, then the prefix inside each block of 1024 flags.  (One workgroup walking all n
+// flags took 0.21 ms per step at 10^6 cells, 6 % of config 4's step.)
+__device__ __forceinline__ int block_inclusive_scan_1024(int value, int* sh)
+{
+    sh[threadIdx.x] = value;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int v = (int)threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += v;
+        __syncthreads();
+    }
+    return sh[threadIdx.x];
+}
+__global__ __launch_bounds__(1024) void k_slot_counts(int n, const int* flag, int* block_sum)
+{
+    __shared__ int sh[1024];
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    const int incl = block_inclusive_scan_1024(i < n ? flag[i] : 0, sh);
+    if (threadIdx.x == 1023) block_sum[blockIdx.x] = incl;
+}
+__global__ __launch_bounds__(1024) void k_slot_block_offsets(int n_blocks, int* block_sum, int n, int* d_n, int n_max)
 {
     __shared__ int sh[1024];
     __shared__ int carry;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
-    for (int base = 0; base < n; base += 1024) {
-        const int i = base + threadIdx.x;
-        const int f = i < n ? flag_to_offset[i] : 0;
-        sh[threadIdx.x] = f;
-        __syncthreads();
-        for (int o = 1; o < 1024; o <<= 1) {
-            const int v = (int)threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
-            __syncthreads();
-            sh[threadIdx.x] += v;
-            __syncthreads();
-        }
-        const int incl = sh[threadIdx.x];
-        if (i < n) flag_to_offset[i] = f ? carry + incl - f : -1;
+    for (int base = 0; base < n_blocks; base += 1024) {
+        const int b = base + threadIdx.x;
+        const int sum = b < n_blocks ? block_sum[b] : 0;
+        const int incl = block_inclusive_scan_1024(sum, sh);
+        if (b < n_blocks) block_sum[b] = carry + incl - sum;  // daughters of all blocks before b
         __syncthreads();
         if (threadIdx.x == 1023) carry += incl;
         __syncthreads();
@@ -353,6 +367,14 @@ __global__ __launch_bounds__(1024) void k_daughter_slots(int n, int* flag_to_off
         D_ASSERT(n + carry <= n_max);
         *d_n = n + carry;
     }
+}
+__global__ __launch_bounds__(1024) void k_daughter_slots(int n, int* flag_to_offset, const int* block_offset)
+{
+    __shared__ int sh[1024];
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    const int f = i < n ? flag_to_offset[i] : 0;
+    const int incl = block_inclusive_scan_1024(f, sh);
+    if (i < n) flag_to_offset[i] = f ? block_offset[blockIdx.x] + incl - f : -1;
 }
 template<typename Rule>
 __global__ void k_daughters(double mean_dist, unsigned seed, unsigned step, int n, const int* offset,
@@ -367,9 +389,14 @@ inline void proliferate(float rate, double mean_dist, unsigned seed, unsigned st
     typename Rule::Pt* X, float3* old_v, int* d_n, int* type, int* mes_nbs, int* epi_nbs,
     int* scratch, int n_max)
 {
+    if (n <= 0) return;
     const int blocks = (n + 255) / 256;
     k_mothers<Rule><<<blocks, 256>>>(rate, seed, step, n, X, type, mes_nbs, epi_nbs, scratch);
-    k_daughter_slots<<<1, 1024>>>(n, scratch, d_n, n_max);
+    const int slot_blocks = (n + 1023) / 1024;
+    int* block_sum = scratch + n_max;  // behind the n_max flags (models_harness.inc allocates both)
+    k_slot_counts<<<slot_blocks, 1024>>>(n, scratch, block_sum);
+    k_slot_block_offsets<<<1, 1024>>>(slot_blocks, block_sum, n, d_n, n_max);
+    k_daughter_slots<<<slot_blocks, 1024>>>(n, scratch, block_sum);
     k_daughters<Rule><<<blocks, 256>>>(
         mean_dist, seed, step, n, scratch, X, old_v, type, mes_nbs, epi_nbs);
 }
