@@ -168,3 +168,27 @@ def test_config5_ten_million_cells_on_one_gpu(device):
         step = np.linalg.norm(X - X0, axis=1)
         assert 0 < step.max() < 0.5
         check_grid(*s.grid(), n, gs)
+
+
+def test_largest_system_the_cube_ids_allow(device):
+    """75 M cells: random_sphere(0.5) of radius 122 fills the largest grid binary32 cube ids can
+    address exactly (grid_size <= 256, YA_MAX_GRID_SIZE) -- byte offsets pass 2^31, the grid
+    holds 1.6e7 cubes.  One take_step, then the size-independent invariants."""
+    n, gs = 75_000_000, 250
+    with Solution("springs_grid", n, gs, 1.0, lib=device) as s:
+        s.random_sphere(0.5, 42)
+        com0 = s.h_X[:n].astype(np.float64).mean(axis=0)
+        reach0 = np.abs(s.h_X[:n]).max()
+        assert reach0 < gs // 2 - 2
+        s.take_step(0.001, 1)
+        assert s.get_d_n() == n
+        X = s.positions()
+        assert np.isfinite(X).all()
+        assert np.abs(X.astype(np.float64).mean(axis=0) - com0).max() <= 1e-5 * reach0
+        cube_id, point_id, start, end = s.grid()
+        cube_id = cube_id[:n]
+        assert (np.diff(cube_id) >= 0).all(), "keys not sorted"
+        counts = np.bincount(cube_id, minlength=gs ** 3)
+        assert counts.sum() == n and 5 < counts[counts > 0].mean() < 15
+        occupied = counts > 0
+        assert np.array_equal(end[:gs ** 3][occupied] - start[:gs ** 3][occupied] + 1, counts[occupied])
