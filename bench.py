@@ -11,11 +11,15 @@ update) over every cell of a random_sphere(0.5, seed 42) system with the
 (cube_size 1), friction_w_neighbour, dt = 0.001.  One cell-update = one cell
 advanced by one take_step.
 
-  N = 1   the 1 M-cell configuration the metric is quoted on ("scaling": "weak",
-          the headline line; --cells-total 10000000 gives the 1-GPU 10 M point).
+  N = 1   the 1 M-cell configuration the metric is quoted on (the headline line;
+          --cells-total 10000000 gives the 1-GPU 10 M point).
   N > 1   north_star's multi-GPU configuration: ONE 10 M-cell system cut into N
           z-slabs, one slab per GPU, ghost layers exchanged point-to-point with
           RCCL send/recv each Heun stage ("scaling": "strong": total work fixed).
+          The base of that strong-scaling curve is NOT the N = 1 line (a 1 M-cell
+          system: 1.5e9 c-u/s) but the same 10 M-cell system on one GPU (1.9e9):
+          rank 0 measures it on its own GPU after the timed region and the line
+          carries it as `one_gpu_same_system` with `speedup_vs_one_gpu_same_system`.
           Started either by torch.distributed.run (RANK / WORLD_SIZE in the
           environment) or by this script itself: without WORLD_SIZE it starts the
           N rank processes (before anything touches a GPU) and relays rank 0's line.
@@ -110,6 +114,9 @@ def parse(argv=None):
     ap.add_argument("--dist", type=float, default=0.5, help="random_sphere spacing")
     ap.add_argument("--cpu-steps", type=int, default=4, help="oracle steps for cpu_baseline (4 steps of 1 M cells: ~12 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-one-gpu-reference", action="store_true",
+                    help="N > 1: skip rank 0's untimed run of the same whole system on one GPU "
+                         "(the base of the strong-scaling curve)")
     ap.add_argument("--model", default="springs_grid",
                     help="named model of the harness (default: the headline springs_grid)")
     ap.add_argument("--dt", type=float, default=0.001)
@@ -439,6 +446,23 @@ def main(argv=None):
 
     elapsed = reduce_over_ranks(elapsed, take_max=True)
 
+    # The base of the strong-scaling curve: the SAME whole system, undivided, on one GPU (rank
+    # 0's), same step counts, measured here and now -- outside the timed region.
+    one_gpu = None
+    if slab_path and world > 1 and not args.no_one_gpu_reference:
+        if rank == 0:
+            my_slab.close()
+            with Solution("springs_grid", n_total, gs, 1.0) as whole:
+                whole.random_sphere(args.dist, 42)
+                whole.set_param("force_variant", args.force_variant)
+                whole.take_step(dt, args.warmup)
+                whole.synchronize()
+                t1 = time.perf_counter()
+                whole.take_step(dt, args.steps)
+                whole.synchronize()
+                one_gpu = n_total * args.steps / (time.perf_counter() - t1)
+        barrier()
+
     if rank == 0:
         value = n_total * args.steps / elapsed
         force_s = force_ms / 1e3 / max(launches, 1)
@@ -457,7 +481,12 @@ def main(argv=None):
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak" if world == 1 else "strong",
+            # N > 1: one 10 M-cell system over N GPUs (total work fixed).  N = 1 is the 1 M-cell
+            # headline and NOT the base of that curve: see one_gpu_same_system on the N > 1 lines.
+            "scaling": "strong",
+            "scaling_note": ("single-GPU headline (1 M cells); the N > 1 lines run ONE %d-cell system and carry "
+                             "their own 1-GPU base (one_gpu_same_system)" % MULTI_GPU_CELLS) if world == 1 else
+                            "strong scaling of one %d-cell system; base = one_gpu_same_system, not the N = 1 line" % n_total,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic: random_sphere(%g) seed 42, glibc rand()" % args.dist,
@@ -508,6 +537,9 @@ def main(argv=None):
                 "fp32_valu_peak_TFLOPs": FP32_VALU_PEAK_TFLOPS,
             },
         }
+        if world > 1:
+            out["one_gpu_same_system"] = one_gpu
+            out["speedup_vs_one_gpu_same_system"] = value / one_gpu if one_gpu else None
         if counters.get("stale_counters"):
             out["roofline"]["stale_counters"] = True
         if world == 1 and not args.slab and not args.no_cpu_baseline:

@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void link(const Pt* __restrict__ d_X, Pt* d_dX
 //   1. link_linear_eval: one thread per link slot computes the link's force once and emits
 //      two (cell, entry) pairs, entry 2i for endpoint a (gets -f) and 2i + 1 for b (gets +f);
 //      inert or unused slots emit a key that sorts last;
-//   2. a stable radix sort of the pairs by cell (rocPRIM, 24 key bits);
+//   2. a stable radix sort of the pairs by cell (rocPRIM, all 32 key bits);
 //   3. link_linear_apply: the first entry of every cell's segment sums the segment in sorted
 //      (= link slot) order and adds it to d_dX with a plain store.  Segments are cut every
 //      256 entries so that a hub cell cannot serialise a thread; only pieces of such cut
@@ -190,8 +190,11 @@ __global__ __launch_bounds__(256) void link(const Pt* __restrict__ d_X, Pt* d_dX
 // Used from YA_LINKS_SEGMENTED_MIN link slots up (see there).  Custom Link_force functors
 // do their own atomics on d_dX and keep the one-thread-per-link kernel.
 namespace ya {
-constexpr unsigned LINK_DEAD_KEY = 0xFFFFFFu;  // cells are numbered below 2^24 - 1
-constexpr int LINK_KEY_BITS = 24;
+// All 32 key bits are sorted: cell ids are ints, so every id a model can hold is below the dead
+// key (a 24-bit sort was one radix pass cheaper, but ids from 2^24 - 1 up -- a 75 M-cell system
+// has them -- would have been merged with other cells or dropped).
+constexpr unsigned LINK_DEAD_KEY = 0xFFFFFFFFu;
+constexpr int LINK_KEY_BITS = 32;
 constexpr int LINK_SEGMENT_CUT = 256;
 
 template<typename Pt>
@@ -208,7 +211,7 @@ __global__ __launch_bounds__(256) void link_linear_eval(const Pt* __restrict__ d
     if (i < n_links) l = d_link[i];
     unsigned key_a = LINK_DEAD_KEY, key_b = LINK_DEAD_KEY;
     if (l.a != l.b) {
-        D_ASSERT((unsigned)l.a < LINK_DEAD_KEY && (unsigned)l.b < LINK_DEAD_KEY);
+        D_ASSERT(l.a >= 0 && l.b >= 0);
         const Pt r = d_X[l.a] - d_X[l.b];
         const float dist = sqrtf(fmaf(r.z, r.z, fmaf(r.y, r.y, r.x * r.x)));
         force[i] = float3{strength * r.x / dist, strength * r.y / dist, strength * r.z / dist};

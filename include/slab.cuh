@@ -3,7 +3,10 @@
 // Solution<Pt, Slab_grid_solver> is Solution<Pt, Grid_solver>.
 //
 //     ya_comm* comm;
-//     ya_comm_create_from_env(1, &comm);                       // RANK / WORLD_SIZE / MASTER_* (torchrun, mpirun wrappers ...)
+//     ya_comm_create_from_env(1, &comm);                       // RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun ...):
+//                                                              // selects GPU LOCAL_RANK, then ncclCommInitRank -- call it
+//                                                              // BEFORE constructing the Solution (its arrays live on the
+//                                                              // device that is current then)
 //     Solution<float3, Slab_grid_solver> cells{n_max, grid_size, cube_size};
 //     ... fill cells.h_X[0 .. n_own) with THIS rank's cells (z in [z_lo, z_hi)), *cells.h_n = n_own ...
 //     cells.copy_to_device();

@@ -309,15 +309,22 @@ class Vtk_input {
     std::string file_name;
     std::string text;  // the whole file: sections are located and parsed in memory
 
-    // (Re)load the file if it is not the size held in memory: sections may be appended to a
-    // file after this object was made (the reference opens the file anew for every read,
-    // and its tests/test_vtk.cu:56-59 relies on that).
+    // (Re)load the file unless it still has the size and modification time of the copy held
+    // in memory: sections may be appended to a file after this object was made, or the file
+    // rewritten with other values of the same length (the reference opens the file anew for
+    // every read, and its tests/test_vtk.cu:56-59 relies on that).
+    long long loaded_sec = -1, loaded_nsec = -1;
     void load()
     {
         struct stat info;
         const bool there = stat(file_name.c_str(), &info) == 0;
         assert(there and "vtk file not found");
-        if (!there or (size_t)info.st_size == text.size()) return;
+        if (!there) return;
+        if ((size_t)info.st_size == text.size() and (long long)info.st_mtim.tv_sec == loaded_sec and
+            (long long)info.st_mtim.tv_nsec == loaded_nsec)
+            return;
+        loaded_sec = (long long)info.st_mtim.tv_sec;
+        loaded_nsec = (long long)info.st_mtim.tv_nsec;
         std::ifstream in(file_name, std::ios::binary);
         assert(in.is_open());
         text.resize((size_t)info.st_size);

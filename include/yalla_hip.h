@@ -197,7 +197,11 @@ int ya_comm_unique_id(void* id_out_128_bytes);
 int ya_comm_create(const void* id_128_bytes, int rank, int world, ya_comm** out);
 /* The same with the id passed from rank 0 over TCP: RANK, WORLD_SIZE, MASTER_ADDR and
  * MASTER_PORT from the environment (the variables torch.distributed.run sets); rank 0 listens
- * on MASTER_PORT + port_offset.  For model programs without any other launcher support. */
+ * on MASTER_PORT + port_offset (and gives up after ten minutes without a connection).  For
+ * model programs without any other launcher support.  With WORLD_SIZE > 1 the calling process
+ * is put on GPU LOCAL_RANK (default RANK) modulo the visible devices first, unless it already
+ * left device 0 itself or YALLA_KEEP_DEVICE=1: one process per GPU, RCCL refuses two ranks on
+ * one.  Returns 997 if that device cannot be selected, 998 for rendezvous failures. */
 int ya_comm_create_from_env(int port_offset, ya_comm** out);
 int ya_comm_destroy(ya_comm* comm);
 int ya_comm_rank(const ya_comm* comm);

@@ -85,3 +85,6 @@ def test_self_launched_two_ranks_on_one_gpu(device):
     assert out["config"]["total_cells"] == 300000 and out["config"]["cells_per_gpu"] == 150000
     assert out["value"] > 0 and out["unit"] == "cell-updates/s"
     assert out["roofline"]["achieved"] > 0 and "cpu_baseline" not in out
+    # the base of the strong-scaling curve travels with the line: the same system on one GPU
+    assert out["one_gpu_same_system"] > 0
+    assert abs(out["speedup_vs_one_gpu_same_system"] - out["value"] / out["one_gpu_same_system"]) < 1e-9

@@ -55,3 +55,11 @@ def test_vtk_output_at_a_million_cells():
     model's output loop with the steps in a worker thread (examples/branching.cu:263-280): same
     frames, same final state as the serial loop."""
     run("test_vtk_speed", "ALL VTK SPEED TESTS PASSED")
+
+
+@pytest.mark.gpu
+def test_link_forces_with_cell_ids_beyond_2_to_24():
+    """Links::link_forces (reference links.cuh:98-140) on cells whose ids share their low 24 bits
+    or equal the former dead key 0xFFFFFF: segmented-sum path (32 key bits) and atomics path
+    against a host evaluation."""
+    run("test_links_big_ids", "ALL BIG-ID LINK TESTS PASSED")

@@ -251,3 +251,28 @@ def test_postponed_migration_device(device):
     """Cells that left their slab are handed over every 4th step only (what bench.py does)."""
     moved = check(device, 40000, 3, 12, 0.004, device="hip", migrate_every=4)
     assert moved >= 0
+
+
+@pytest.mark.gpu
+def test_eight_slabs_of_a_million_cells_native_sequencing(device):
+    """north_star's decomposition at scale on one GPU: 1.2 M cells in EIGHT slabs, every slab a
+    Solution<float3, Slab_grid_solver> stepped by its own host thread through the native sequencing
+    (tools/slab_rehearsal.cu: Slab_grid_solver::take_step with a callback transport, migration
+    every 4th step), against the undivided system after the same 8 take_steps.  Tolerance: 1e-5
+    of the system's extent, with tests/fuzz_slab.py's budget for pairs within rounding of the
+    cut-off (each moves two cells by 0.5 dt)."""
+    import json
+    exe = os.path.join(ROOT, "tools", "slab_rehearsal")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "tools"), "slab_rehearsal"], check=True, capture_output=True)
+    n, steps, warmup, dt = 1_200_000, 6, 2, 0.001
+    proc = subprocess.run([exe, str(n), "8", str(steps), str(warmup), "4"], capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-2000:]
+    out = json.loads(proc.stdout.strip().splitlines()[-1])
+    assert out["world"] == 8 and len(out["slabs"]) == 8 and out["cells_after"] == n
+    assert min(s["n_own"] for s in out["slabs"]) > 0.9 * n / 8
+    assert all(s["n_ghost"] > 0 for s in out["slabs"])
+    par = out["parity"]
+    assert par["take_steps"] == steps + warmup and par["cells_missing"] == 0
+    assert par["cells_beyond_1e-5"] <= max(4, n // 2000), par
+    assert par["max_abs_diff"] <= 2.0 * (steps + warmup) * dt, par

@@ -1,0 +1,273 @@
+// Rehearsal of north_star's multi-GPU configuration on ONE GPU: a 10 M-cell springs system cut
+// into W z-slabs, every slab a Solution<float3, Slab_grid_solver> stepped by its own host thread
+// through the NATIVE sequencing (Slab_grid_solver::take_step = slab_step) with a callback
+// transport, exactly as W ranks would -- except that the slabs share one GPU.  So that each
+// slab's device time is what it would be with a GPU of its own, the threads take turns: a
+// thread holds the GPU from the moment a transport call returns until it enters the next one
+// (where it drains the device and stops its clock), and the transport itself -- the copies
+// between the slabs' message buffers and the sum of the all-reduce -- runs outside everyone's
+// clock.  What the clocks hold is therefore the COMPUTE side of a rank's step, host launch
+// latencies included, transport excluded.
+//
+//   slab_rehearsal [cells] [world] [steps] [warmup] [migrate_every]
+//
+// Output: one JSON object -- the undivided system's ms/step on the same GPU, per slab n_own /
+// n_ghost / ms per step and per segment, the critical path (per segment the slowest slab: the
+// exchange and the all-reduce are synchronisation points) and
+// projected_speedup_compute_only = undivided / critical path.  A PROJECTION: RCCL latency and
+// xGMI transfer times are not in it (tools/comm_probe measures what one rank can of those).
+#include "../include/dtypes.cuh"
+#include "../include/inits.cuh"
+#include "../include/slab.cuh"
+#include "../include/solvers.cuh"
+
+#include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+__device__ float3 spring(float3 Xi, float3 r, float dist, int i, int j)  // examples/springs.cu:14-21
+{
+    float3 dF{0.f, 0.f, 0.f};
+    if (i == j) return dF;
+    return r * (0.5f - dist) / dist;
+}
+
+using Clock = std::chrono::steady_clock;
+using Slab = Solution<float3, Slab_grid_solver>;
+constexpr int SEGMENTS = 8;  // per step: pack | rhs 1 | update 1 + pack | rhs 2 | update 2 (+ migrate pack) | unpack
+
+struct Barrier {
+    std::mutex m;
+    std::condition_variable cv;
+    int waiting = 0, generation = 0, parties;
+    explicit Barrier(int n) : parties(n) {}
+    void wait()
+    {
+        std::unique_lock<std::mutex> lock(m);
+        const int gen = generation;
+        if (++waiting == parties) {
+            waiting = 0;
+            generation++;
+            cv.notify_all();
+        } else
+            cv.wait(lock, [&] { return gen != generation; });
+    }
+};
+
+struct Shared {
+    int world;
+    Barrier barrier;
+    std::mutex gpu;  // whoever holds it has the device to itself
+    std::vector<const void*> send_lo, send_hi;
+    std::vector<float*> sums;
+    bool timing = false;
+    explicit Shared(int w) : world(w), barrier(w), send_lo(w), send_hi(w), sums(w) {}
+};
+
+struct Rank {
+    Shared* shared;
+    int rank;
+    Clock::time_point started;
+    int segment = 0;
+    double seconds[SEGMENTS] = {0};
+    void stop()  // the device is drained, the clock stopped, the GPU handed on
+    {
+        (void)hipDeviceSynchronize();
+        if (shared->timing && segment < SEGMENTS)
+            seconds[segment] += std::chrono::duration<double>(Clock::now() - started).count();
+        segment++;
+        shared->gpu.unlock();
+    }
+    void start()
+    {
+        shared->gpu.lock();
+        started = Clock::now();
+    }
+};
+
+static int exchange_cb(void* ctx, int kind, const void* send_lo, void* recv_lo, const void* send_hi, void* recv_hi,
+    long bytes)
+{
+    Rank& me = *(Rank*)ctx;
+    Shared& sh = *me.shared;
+    me.stop();
+    sh.send_lo[me.rank] = send_lo;
+    sh.send_hi[me.rank] = send_hi;
+    sh.barrier.wait();
+    // what RCCL send/recv would move over xGMI: device-to-device copies, outside the clocks
+    if (recv_lo && me.rank > 0) (void)hipMemcpy(recv_lo, sh.send_hi[me.rank - 1], (size_t)bytes, hipMemcpyDeviceToDevice);
+    if (recv_hi && me.rank + 1 < sh.world)
+        (void)hipMemcpy(recv_hi, sh.send_lo[me.rank + 1], (size_t)bytes, hipMemcpyDeviceToDevice);
+    (void)hipDeviceSynchronize();
+    sh.barrier.wait();
+    me.start();
+    return 0;
+}
+
+static int allreduce_cb(void* ctx, float* buf, int count)
+{
+    Rank& me = *(Rank*)ctx;
+    Shared& sh = *me.shared;
+    me.stop();
+    sh.sums[me.rank] = buf;
+    sh.barrier.wait();
+    if (me.rank == 0) {
+        std::vector<float> total(count, 0.f), part(count);
+        for (int r = 0; r < sh.world; r++) {
+            (void)hipMemcpy(part.data(), sh.sums[r], count * sizeof(float), hipMemcpyDeviceToHost);
+            for (int k = 0; k < count; k++) total[k] += part[k];
+        }
+        for (int r = 0; r < sh.world; r++)
+            (void)hipMemcpy(sh.sums[r], total.data(), count * sizeof(float), hipMemcpyHostToDevice);
+    }
+    sh.barrier.wait();
+    me.start();
+    return 0;
+}
+
+int main(int argc, char** argv)
+{
+    const int n = argc > 1 ? atoi(argv[1]) : 10000000;
+    const int world = argc > 2 ? atoi(argv[2]) : 8;
+    const int steps = argc > 3 ? atoi(argv[3]) : 16;
+    const int warmup = argc > 4 ? atoi(argv[4]) : 3;
+    const int migrate_every = argc > 5 ? atoi(argv[5]) : 16;
+    const float dt = 0.001f, dist = 0.5f;
+    const float radius = powf(n / 0.64f, 1.f / 3) * dist / 2;
+    const int gs = std::max(2 * ((int)radius + 3), 8);
+
+    // the undivided system, same GPU, same step count
+    std::vector<float3> X0((size_t)n), X_whole((size_t)n);
+    double whole_ms;
+    {
+        Solution<float3, Grid_solver> whole{n, gs, 1.f};
+        random_sphere(dist, whole, 0, 42);
+        std::copy(whole.h_X, whole.h_X + n, X0.begin());
+        for (int s = 0; s < warmup; s++) whole.take_step<spring>(dt);
+        (void)hipDeviceSynchronize();
+        const auto t0 = Clock::now();
+        for (int s = 0; s < steps; s++) whole.take_step<spring>(dt);
+        (void)hipDeviceSynchronize();
+        whole_ms = std::chrono::duration<double>(Clock::now() - t0).count() / steps * 1e3;
+        whole.copy_to_host();  // after warmup + steps take_steps: what the slabs must reproduce
+        std::copy(whole.h_X, whole.h_X + n, X_whole.begin());
+    }
+
+    const ya::Slab_plan plan = ya::slab_plan(X0.data(), n, world, 1.f);
+    if (plan.error) {
+        printf("{\"error\": \"a slab is thinner than the ghost layer\", \"cells\": %d, \"world\": %d}\n", n, world);
+        return 1;
+    }
+    Shared shared{world};
+    std::vector<std::unique_ptr<Slab>> slabs;
+    std::vector<Rank> ranks(world);
+    for (int r = 0; r < world; r++) {
+        slabs.emplace_back(new Slab{plan.n_max, gs, 1.f});
+        Slab& s = *slabs.back();
+        std::vector<int> gid((size_t)plan.n_own[r]);
+        const int own = ya::slab_own_cells(plan, r, X0.data(), n, s.h_X, gid.data());
+        *s.h_n = own;
+        s.copy_to_device();
+        if (s.slab_init(plan.bounds[r], plan.bounds[r + 1], plan.halo, gid.data(), own) != 0 ||
+            s.slab_setup(r, world, plan.halo_cap, plan.mig_cap) != 0)
+            return 2;
+        s.d_global_id = nullptr;  // spring only compares i with j (as bench.py runs it)
+        ranks[r].shared = &shared;
+        ranks[r].rank = r;
+        s.slab_set_transport(exchange_cb, allreduce_cb, &ranks[r]);
+        s.migrate_every = migrate_every;
+    }
+    X0.clear();
+    X0.shrink_to_fit();
+
+    std::vector<int> ghosts(world, 0), owns(world, 0);
+    // every cell's position after the run, by global id, for the comparison with the undivided system
+    std::vector<float3> X_slabs((size_t)n, float3{NAN, NAN, NAN});
+    std::mutex collect;
+    auto run = [&](int r) {
+        Slab& s = *slabs[r];
+        Rank& me = ranks[r];
+        for (int k = 0; k < warmup + steps; k++) {
+            if (k == warmup) {
+                shared.barrier.wait();
+                if (r == 0) shared.timing = true;
+                shared.barrier.wait();
+            }
+            me.segment = 0;
+            me.start();
+            s.take_step<spring>(dt);
+            me.stop();
+            shared.barrier.wait();
+        }
+        ghosts[r] = s.slab.ghosts[0] + s.slab.ghosts[1];
+        owns[r] = s.slab.n_own;
+        std::lock_guard<std::mutex> lock(collect);
+        std::vector<float> X((size_t)3 * plan.n_max);
+        std::vector<int> gid((size_t)plan.n_max);
+        const int own = s.get_own(X.data(), gid.data());
+        for (int k = 0; k < own; k++) X_slabs[gid[k]] = float3{X[3 * k], X[3 * k + 1], X[3 * k + 2]};
+    };
+    if (world == 1) {
+        // a world of one never calls its transport: the whole step is one segment
+        run(0);
+    } else {
+        std::vector<std::thread> threads;
+        for (int r = 0; r < world; r++) threads.emplace_back(run, r);
+        for (auto& t : threads) t.join();
+    }
+
+    // slabs against the undivided system: 1e-5 of the system's extent, except for the odd pair of
+    // cells whose distance is within rounding of the cut-off (see tests/fuzz_slab.py)
+    double scale = 0, max_diff = 0;
+    long beyond = 0, missing = 0;
+    for (int i = 0; i < n; i++)
+        scale = std::max({scale, (double)std::fabs(X_whole[i].x), (double)std::fabs(X_whole[i].y), (double)std::fabs(X_whole[i].z)});
+    for (int i = 0; i < n; i++) {
+        if (X_slabs[i].x != X_slabs[i].x) {
+            missing++;
+            continue;
+        }
+        const double d = std::max({std::fabs((double)X_slabs[i].x - X_whole[i].x), std::fabs((double)X_slabs[i].y - X_whole[i].y),
+            std::fabs((double)X_slabs[i].z - X_whole[i].z)});
+        max_diff = std::max(max_diff, d);
+        beyond += d > 1e-5 * scale;
+    }
+
+    double critical = 0, slowest_slab = 0;
+    double seg_max[SEGMENTS] = {0};
+    for (int g = 0; g < SEGMENTS; g++) {
+        for (int r = 0; r < world; r++) seg_max[g] = std::max(seg_max[g], ranks[r].seconds[g]);
+        critical += seg_max[g];
+    }
+    printf("{\"cells\": %d, \"world\": %d, \"grid_size\": %d, \"steps\": %d, \"warmup\": %d, \"migrate_every\": %d, "
+           "\"sequencing\": \"native (Slab_grid_solver::take_step), one host thread per slab, slabs take turns on the GPU\", "
+           "\"undivided_ms_per_step\": %.4f, \"halo_cap\": %d, \"slabs\": [",
+        n, world, gs, steps, warmup, migrate_every, whole_ms, plan.halo_cap);
+    long total_own = 0;
+    for (int r = 0; r < world; r++) {
+        double sum = 0;
+        for (int g = 0; g < SEGMENTS; g++) sum += ranks[r].seconds[g];
+        slowest_slab = std::max(slowest_slab, sum);
+        total_own += owns[r];
+        printf("%s{\"rank\": %d, \"n_own\": %d, \"n_ghost\": %d, \"ms_per_step\": %.4f, \"segments_ms\": [", r ? ", " : "",
+            r, owns[r], ghosts[r], sum / steps * 1e3);
+        for (int g = 0; g < SEGMENTS; g++) printf("%s%.4f", g ? ", " : "", ranks[r].seconds[g] / steps * 1e3);
+        printf("]}");
+    }
+    printf("], \"segment_names\": [\"pack 1\", \"unpack + build + force + sum 1\", \"update 1 + pack 2\", "
+           "\"unpack + build + force + sum 2\", \"update 2 (+ migrate pack)\", \"migrate unpack\", \"-\", \"-\"], "
+           "\"segment_max_ms\": [");
+    for (int g = 0; g < SEGMENTS; g++) printf("%s%.4f", g ? ", " : "", seg_max[g] / steps * 1e3);
+    printf("], \"parity\": {\"take_steps\": %d, \"cells_missing\": %ld, \"cells_beyond_1e-5\": %ld, \"max_abs_diff\": %.3g, "
+           "\"scale\": %.4g}", warmup + steps, missing, beyond, max_diff, scale);
+    printf(", \"cells_after\": %ld, \"slowest_slab_ms_per_step\": %.4f, \"critical_path_ms_per_step\": %.4f, "
+           "\"projected_speedup_compute_only\": %.3f, \"note\": \"projection: compute side only, no RCCL latency, no xGMI transfer time\"}\n",
+        total_own, slowest_slab / steps * 1e3, critical / steps * 1e3, whole_ms / (critical / steps * 1e3));
+    return total_own == n ? 0 : 3;
+}

@@ -10,6 +10,7 @@
 #include <errno.h>
 #include <netdb.h>
 #include <netinet/in.h>
+#include <poll.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -42,12 +43,17 @@ struct Rccl {
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 
+Rccl* load_rccl();
 Rccl* rccl()
 {
+    // loaded once, by whichever thread asks first (function-local static: thread-safe)
+    static Rccl* const loaded = load_rccl();
+    return loaded;
+}
+
+Rccl* load_rccl()
+{
     static Rccl r;
-    static bool tried = false;
-    if (tried) return r.lib ? &r : nullptr;
-    tried = true;
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char* name : names) {
         r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
@@ -88,6 +94,16 @@ int rccl_error(const char* what, ncclResult_t code)
     do {                                          \
         const ncclResult_t rc_ = (call);          \
         if (rc_ != 0) return rccl_error(what, rc_); \
+    } while (0)
+// inside ncclGroupStart / ncclGroupEnd: a failed call must still close the group, or the
+// communicator stays unusable
+#define YA_RCCL_IN_GROUP(call, what)              \
+    do {                                          \
+        const ncclResult_t rc_ = (call);          \
+        if (rc_ != 0) {                           \
+            (void)r->GroupEnd();                  \
+            return rccl_error(what, rc_);         \
+        }                                         \
     } while (0)
 
 int send_all(int fd, const void* data, size_t bytes)
@@ -172,6 +188,27 @@ int ya_comm_create_from_env(int port_offset, ya_comm** out)
     const int rank = s_rank ? atoi(s_rank) : 0;
     const int world = s_world ? atoi(s_world) : 1;
     if (world <= 1) return ya_comm_create(nullptr, 0, 1, out);
+    // One process per GPU: unless the program has already chosen its device (YALLA_KEEP_DEVICE=1,
+    // or it called hipSetDevice to something other than 0), rank r of a node takes GPU
+    // LOCAL_RANK (torchrun, bench.py's launcher) -- else every rank would sit on device 0 and
+    // ncclCommInitRank refuses two ranks on one GPU.
+    {
+        int current = 0, count = 0;
+        (void)hipGetDevice(&current);
+        (void)hipGetDeviceCount(&count);
+        const char* s_local = getenv("LOCAL_RANK");
+        const char* keep = getenv("YALLA_KEEP_DEVICE");
+        if (!(keep && atoi(keep)) && current == 0 && count > 1) {
+            const int local = s_local ? atoi(s_local) : rank;
+            if (hipSetDevice(local % count) != hipSuccess) {
+                fprintf(stderr, "yalla-hip: rank %d cannot select GPU %d of %d\n", rank, local % count, count);
+                return 997;
+            }
+        } else if (count == 1 && !(keep && atoi(keep))) {
+            fprintf(stderr, "yalla-hip: rank %d of %d sees one GPU only: RCCL needs one GPU per rank "
+                            "(set YALLA_KEEP_DEVICE=1 to try anyway)\n", rank, world);
+        }
+    }
     const char* addr = getenv("MASTER_ADDR") ? getenv("MASTER_ADDR") : "127.0.0.1";
     const int port = (getenv("MASTER_PORT") ? atoi(getenv("MASTER_PORT")) : 29500) + port_offset;
     char id[YA_COMM_ID_BYTES];
@@ -191,6 +228,16 @@ int ya_comm_create_from_env(int port_offset, ya_comm** out)
             return 998;
         }
         for (int k = 1; k < world; k++) {
+            // a rank that died before connecting must not hang rank 0 for ever: ten minutes
+            // (the first import of a big runtime on a fresh box can take two), then give up
+            pollfd waiting{srv, POLLIN, 0};
+            const int ready = poll(&waiting, 1, 600 * 1000);
+            if (ready <= 0) {
+                fprintf(stderr, "yalla-hip: rank 0 waited ten minutes for rank connection %d of %d on port %d\n",
+                    k, world - 1, port);
+                close(srv);
+                return 998;
+            }
             const int fd = accept(srv, nullptr, nullptr);
             if (fd < 0 || send_all(fd, id, sizeof(id)) != 0) {
                 fprintf(stderr, "yalla-hip: rank 0 could not hand the id to a rank: %s\n", strerror(errno));
@@ -258,12 +305,12 @@ int ya_comm_exchange(ya_comm* c, const void* d_send_lo, void* d_recv_lo, const v
         return (int)hipErrorInvalidValue;
     YA_RCCL(r->GroupStart(), "ncclGroupStart");
     if (lo) {
-        YA_RCCL(r->Send(d_send_lo, bytes, NCCL_INT8, c->rank - 1, c->comm, st), "ncclSend (lower slab)");
-        YA_RCCL(r->Recv(d_recv_lo, bytes, NCCL_INT8, c->rank - 1, c->comm, st), "ncclRecv (lower slab)");
+        YA_RCCL_IN_GROUP(r->Send(d_send_lo, bytes, NCCL_INT8, c->rank - 1, c->comm, st), "ncclSend (lower slab)");
+        YA_RCCL_IN_GROUP(r->Recv(d_recv_lo, bytes, NCCL_INT8, c->rank - 1, c->comm, st), "ncclRecv (lower slab)");
     }
     if (hi) {
-        YA_RCCL(r->Send(d_send_hi, bytes, NCCL_INT8, c->rank + 1, c->comm, st), "ncclSend (upper slab)");
-        YA_RCCL(r->Recv(d_recv_hi, bytes, NCCL_INT8, c->rank + 1, c->comm, st), "ncclRecv (upper slab)");
+        YA_RCCL_IN_GROUP(r->Send(d_send_hi, bytes, NCCL_INT8, c->rank + 1, c->comm, st), "ncclSend (upper slab)");
+        YA_RCCL_IN_GROUP(r->Recv(d_recv_hi, bytes, NCCL_INT8, c->rank + 1, c->comm, st), "ncclRecv (upper slab)");
     }
     YA_RCCL(r->GroupEnd(), "ncclGroupEnd");
     return 0;
@@ -276,8 +323,8 @@ int ya_comm_self_exchange(ya_comm* c, const void* d_send, void* d_recv, size_t b
     if (!r) return 999;
     hipStream_t st = (hipStream_t)stream;
     YA_RCCL(r->GroupStart(), "ncclGroupStart");
-    YA_RCCL(r->Send(d_send, bytes, NCCL_INT8, c->rank, c->comm, st), "ncclSend (self)");
-    YA_RCCL(r->Recv(d_recv, bytes, NCCL_INT8, c->rank, c->comm, st), "ncclRecv (self)");
+    YA_RCCL_IN_GROUP(r->Send(d_send, bytes, NCCL_INT8, c->rank, c->comm, st), "ncclSend (self)");
+    YA_RCCL_IN_GROUP(r->Recv(d_recv, bytes, NCCL_INT8, c->rank, c->comm, st), "ncclRecv (self)");
     YA_RCCL(r->GroupEnd(), "ncclGroupEnd");
     return 0;
 }
