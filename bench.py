@@ -127,6 +127,10 @@ def parse(argv=None):
     ap.add_argument("--force-variant", type=int, default=2,
                     help="2 = grid_force_bits (default), 1 = grid_force (byte FIFO), 0 = grid_force_direct (A/B), "
                          "3 = grid_force_coop (opt-in: 16 lanes per cell, for <= ~5e4 cells)")
+    ap.add_argument("--arith", default="exact", choices=["exact", "fast"],
+                    help="arithmetic tier: exact (default; libyalla_models.so: IEEE binary32 statement by "
+                         "statement, bit-comparable with the oracle) or fast (libyalla_models_fast.so: "
+                         "contracted multiply-adds, bare v_sqrt_f32 / v_rcp_f32; within 1e-5 of exact)")
     ap.add_argument("--backend", default="nccl",
                     help="torch.distributed backend for N > 1 / --slab: nccl (= RCCL), or gloo with "
                          "YALLA_BENCH_DEVICE=0 to rehearse the N-rank path on one GPU (RCCL refuses "
@@ -317,7 +321,14 @@ def main(argv=None):
         else:
             dist.init_process_group(args.backend)
 
-    from yalla_amd.solution import Solution
+    from yalla_amd import _ffi
+    from yalla_amd.solution import Solution as _Solution
+
+    engine = _ffi.device_lib(args.arith)
+
+    def Solution(*a, **kw):   # every system of this run on the chosen arithmetic tier
+        kw.setdefault("lib", engine)
+        return _Solution(*a, **kw)
 
     n_total = args.cells_total or args.cells or (1_000_000 if world == 1 else MULTI_GPU_CELLS)
     gs = args.grid_size or grid_size_for(n_total, args.dist)
@@ -388,7 +399,7 @@ def main(argv=None):
             X0 = whole.h_X[:n_total].copy()
         bounds = slab_mod.slab_bounds(X0[:, 2], world)
         native_step = args.sequencing == "native"
-        my_slab = slab_mod.Slab("springs_grid", X0, rank, world, bounds, gs, cube_size=1.0,
+        my_slab = slab_mod.Slab("springs_grid", X0, rank, world, bounds, gs, cube_size=1.0, lib=engine,
                                 device=f"cuda:{local_rank}", python_buffers=not native_step,
                                 global_ids=False)  # spring only compares i with j
         del X0
@@ -469,7 +480,7 @@ def main(argv=None):
         force_bytes = force_bytes_per_cell(n_floats)
         achieved = n_force * force_bytes / force_s / 1e9 if launches else None
         headline = (world == 1 and not args.slab and args.model == "springs_grid" and n_total == 1_000_000
-                    and args.dist == 0.5 and args.force_variant == 2)
+                    and args.dist == 0.5 and args.force_variant == 2 and args.arith == "exact")
         counters, counters_head = measured_counters("grid_force_1M_springs") if headline else ({}, None)
         gather_bytes = gather_model_bytes_per_cell_update(n_floats, args.dist)
         out = {
@@ -499,6 +510,7 @@ def main(argv=None):
                 "cube_size": 1.0,
                 "step_replayed_as_hipgraph": bool(graph_mode),
                 "force_variant": args.force_variant,
+                "arith": args.arith,
                 "links": n_links if not slab_path else 0,
                 "parallelism": "1 GPU" if world == 1 else
                                f"{world} z-slabs of one {n_total}-cell system, step sequenced "

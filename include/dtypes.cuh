@@ -84,7 +84,10 @@ __host__ __device__ __forceinline__ Pt zero()
 // (ya::check_reciprocal_all): seven instructions instead of fourteen per pair.
 __host__ __device__ __forceinline__ float reciprocal(const float b)
 {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(YA_ARITH_FAST)
+    // fast-arithmetic tier (see ya::exact_sqrt in solvers.cuh): the bare v_rcp_f32, <= 1 ulp
+    return __builtin_amdgcn_rcpf(b);
+#elif defined(__HIP_DEVICE_COMPILE__)
     // The common path runs unconditionally; out-of-range arguments replace its result
     // afterwards (one skipped branch per call instead of a two-sided one).
     const float a = __builtin_fabsf(b);

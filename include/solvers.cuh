@@ -121,8 +121,21 @@ struct alignas((sizeof(Pt) + 4) % 16 == 0 ? 16 : ((sizeof(Pt) + 4) % 8 == 0 ? 8 
 // instructions per interacting pair).  Tiny non-zero arguments take the library
 // path.  Verified against sqrtf for EVERY binary32 argument by
 // tests/test_parity_gpu.py (ya::check_sqrt_all).
+//
+// YA_ARITH_FAST (a build switch for a model's translation unit, together with
+// -ffp-contract=fast): the fast-arithmetic tier.  The pair distance is the bare v_sqrt_f32
+// (<= 1 ulp, as CUDA's norm3df, which the reference calls at solvers.cuh:308,449), `Pt / float`
+// multiplies by the bare v_rcp_f32 (<= 1 ulp), and multiply-adds are contracted as nvcc
+// contracts them for the reference's CUDA build.  Results then agree with the exact tier (and
+// the oracle) to rounding, i.e. far inside north_star's 1e-5 relative on positions
+// (tests/test_fast_arith_gpu.py holds every configuration's functor to that in lock-step), but
+// not bit for bit; cube ids, cell counts and the grid arrays stay bit-exact (they are computed in
+// libyalla_hip.so, which is always built without contraction).  -18 % on the 1 M-cell force launch.
 __device__ __forceinline__ float exact_sqrt(float x)
 {
+#ifdef YA_ARITH_FAST
+    return __builtin_amdgcn_sqrtf(x);
+#endif
     // The common path runs unconditionally; the rare one (a tiny non-zero argument)
     // replaces its result afterwards: one skipped branch per call instead of a two-sided one.
     const float s = __builtin_amdgcn_sqrtf(x);
@@ -834,6 +847,36 @@ __global__ __launch_bounds__(FORCE_BLOCK) void grid_force(const int n,
 // 803 against 853 us at 4 M.  What bounds it is the VALU issue rate.
 // Results are bit-identical to grid_force / grid_force_direct: same candidates, same
 // order, same arithmetic.
+// The friction terms of one pair (solvers.cuh:309-313, :453-458): sum_friction += friction,
+// sum_v += friction * old_v[j].  For the default functor friction_w_neighbour the coefficient
+// is 0 or 1, so the products are selections: `+= nb ? v : +0` gives the bits of the reference's
+// `if (friction != 0) sum += 1.f * v` (1.f * v is v; adding +0 to a sum that started at +0
+// never changes it: such a sum cannot be -0) in 8 instead of 14 instructions per pair
+// (-2.6 % on the 1 M-cell force launch, profiles/r03_force_ab.jsonl).
+template<typename Pt, Pairwise_friction<Pt> pw_friction>
+__device__ __forceinline__ void pair_friction(const Pt& Xi, const Pt& r, const float dist, const int i,
+    const int j, const float4& v, float3& sum_v, float& sum_friction)
+{
+#ifndef YA_NO_FRICTION_SPECIAL
+    if constexpr (pw_friction == &friction_w_neighbour<Pt>) {
+        const bool nb = (i != j) & (dist < 1.f);
+        sum_friction += nb ? 1.f : 0.f;
+        sum_v.x += nb ? v.x : 0.f;
+        sum_v.y += nb ? v.y : 0.f;
+        sum_v.z += nb ? v.z : 0.f;
+    } else
+#endif
+    {
+        const float friction = pw_friction(Xi, r, dist, i, j);
+        sum_friction += friction;
+        if (friction != 0) {
+            sum_v.x += friction * v.x;
+            sum_v.y += friction * v.y;
+            sum_v.z += friction * v.z;
+        }
+    }
+}
+
 namespace bits {
 #ifndef YA_BITS_BLOCK
 #define YA_BITS_BLOCK 64
@@ -869,7 +912,7 @@ __device__ __forceinline__ void shift_in(unsigned& m, const float d2, const floa
 // One pass: up to three candidate segments [b_r, e_r) of the staged cells (LDS indices;
 // empty if b_r >= e_r), at most PASS_BITS bits after padding each to a multiple of four.
 // shift_r turns an LDS index of segment r into a slot of the sorted arrays.
-template<typename Pt, Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction, bool STAGE_V>
+template<typename Pt, Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction, bool STAGE_V, bool GLOBAL_IDS>
 __device__ __forceinline__ void pass(const Entry<Pt>* __restrict__ sh_e, const float4* __restrict__ sh_v,
     Lds_word* const words,
     const int b0, const int e0, const int b1, const int e1, const int b2, const int e2,
@@ -935,15 +978,9 @@ __device__ __forceinline__ void pass(const Entry<Pt>* __restrict__ sh_e, const f
     {                                                                                  \
         Pt r = Xi - other_.X;                                                          \
         float dist = dist3(r.x, r.y, r.z);                                             \
-        const int j = global_id ? global_id[other_.id] : other_.id;                    \
+        const int j = GLOBAL_IDS ? global_id[other_.id] : other_.id;                   \
         F += pw_int(Xi, r, dist, i, j);                                                \
-        float friction = pw_friction(Xi, r, dist, i, j);                               \
-        sum_friction += friction;                                                      \
-        if (friction != 0) {                                                           \
-            sum_v.x += friction * v_.x;                                                \
-            sum_v.y += friction * v_.y;                                                \
-            sum_v.z += friction * v_.z;                                                \
-        }                                                                              \
+        pair_friction<Pt, pw_friction>(Xi, r, dist, i, j, v_, sum_v, sum_friction);    \
     }
     while (cur != 0 || left > 0) {
         const bool refill = cur == 0;  // then left > 0
@@ -977,7 +1014,10 @@ __device__ __forceinline__ void pass(const Entry<Pt>* __restrict__ sh_e, const f
 }
 }  // namespace bits
 
-template<typename Pt, Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction, bool STAGE_V = false>
+// GLOBAL_IDS (z-slab decomposition): functors get global_id[local index]; a template parameter
+// rather than a null test so that the single-GPU kernel carries neither the test nor the gather.
+template<typename Pt, Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction, bool STAGE_V = false,
+    bool GLOBAL_IDS = false>
 __global__ __launch_bounds__(bits::BLOCK) void grid_force_bits(const int n,
     const Entry<Pt>* __restrict__ sorted, const float4* __restrict__ sorted_v,
     const int* __restrict__ cube_id, const int* __restrict__ offs, const int gs,
@@ -1011,7 +1051,7 @@ __global__ __launch_bounds__(bits::BLOCK) void grid_force_bits(const int n,
     }
     if (!__syncthreads_or(active)) return;  // a workgroup of ghosts only
     // functors see GLOBAL ids in a slab decomposition (they index per-cell model arrays)
-    const int gi = global_id && active ? global_id[i] : i;
+    const int gi = GLOBAL_IDS && active ? global_id[i] : i;
     Pt F = ya::zero<Pt>();
     float3 sum_v{0.f, 0.f, 0.f};
     float sum_friction = 0;
@@ -1053,7 +1093,7 @@ __global__ __launch_bounds__(bits::BLOCK) void grid_force_bits(const int n,
             const int bits_needed = (max(se[0] - sb[0], 0) + 3 & ~3) + (max(se[1] - sb[1], 0) + 3 & ~3) +
                                     (max(se[2] - sb[2], 0) + 3 & ~3);
             if (!__any(bits_needed > bits::PASS_BITS)) {
-                bits::pass<Pt, pw_int, pw_friction, STAGE_V>(sh_e, sh_v, words, sb[0], se[0], sb[1], se[1], sb[2],
+                bits::pass<Pt, pw_int, pw_friction, STAGE_V, GLOBAL_IDS>(sh_e, sh_v, words, sb[0], se[0], sb[1], se[1], sb[2],
                     se[2], shift[0], shift[1], shift[2], sorted_v, Xi, gi, cut2, F, sum_v, sum_friction,
                     global_id);
             } else {
@@ -1065,7 +1105,7 @@ __global__ __launch_bounds__(bits::BLOCK) void grid_force_bits(const int n,
                     const int rs = r == 0 ? shift[0] : (r == 1 ? shift[1] : shift[2]);
 #pragma unroll 1
                     for (int b = rb; __any(b < re); b += bits::PASS_BITS)
-                        bits::pass<Pt, pw_int, pw_friction, STAGE_V>(sh_e, sh_v, words, b, min(re, b + bits::PASS_BITS),
+                        bits::pass<Pt, pw_int, pw_friction, STAGE_V, GLOBAL_IDS>(sh_e, sh_v, words, b, min(re, b + bits::PASS_BITS),
                             0, 0, 0, 0, rs, 0, 0, sorted_v, Xi, gi, cut2, F, sum_v, sum_friction, global_id);
                 }
             }
@@ -2160,16 +2200,25 @@ protected:
             YA_COOP_LAUNCH(8);
         } else if (lanes == 4) {
             YA_COOP_LAUNCH(4);
-        } else if (force_variant >= 2 && n <= stage_v_max) {
-            YA_FORCE_LAUNCH((ya::grid_force_bits<Pt, pw_int, pw_friction, true>),
-                (n + ya::bits::BLOCK - 1) / ya::bits::BLOCK, ya::bits::BLOCK, n, d_cells, d_cells_v,
-                (const int*)grid.d_cube_id, grid.offsets(), grid.grid_size, grid.n_cubes, cut2, d_dX,
-                has_gen, n_active, d_dX_in_cell_order, (const int*)d_global_id);
         } else if (force_variant >= 2) {
-            YA_FORCE_LAUNCH((ya::grid_force_bits<Pt, pw_int, pw_friction>),
-                (n + ya::bits::BLOCK - 1) / ya::bits::BLOCK, ya::bits::BLOCK, n, d_cells, d_cells_v,
-                (const int*)grid.d_cube_id, grid.offsets(), grid.grid_size, grid.n_cubes, cut2, d_dX,
-                has_gen, n_active, d_dX_in_cell_order, (const int*)d_global_id);
+#define YA_BITS_LAUNCH(stage_v_, gids_)                                                        \
+    YA_FORCE_LAUNCH((ya::grid_force_bits<Pt, pw_int, pw_friction, stage_v_, gids_>),           \
+        (n + ya::bits::BLOCK - 1) / ya::bits::BLOCK, ya::bits::BLOCK, n, d_cells, d_cells_v,   \
+        (const int*)grid.d_cube_id, grid.offsets(), grid.grid_size, grid.n_cubes, cut2, d_dX,  \
+        has_gen, n_active, d_dX_in_cell_order, (const int*)d_global_id)
+            const bool stage_v = n <= stage_v_max;
+            if (d_global_id) {
+                if (stage_v) {
+                    YA_BITS_LAUNCH(true, true);
+                } else {
+                    YA_BITS_LAUNCH(false, true);
+                }
+            } else if (stage_v) {
+                YA_BITS_LAUNCH(true, false);
+            } else {
+                YA_BITS_LAUNCH(false, false);
+            }
+#undef YA_BITS_LAUNCH
         } else if (force_variant == 0) {
             YA_FORCE_LAUNCH((ya::grid_force_direct<Pt, pw_int, pw_friction>), blocks, ya::FORCE_BLOCK, n,
                 d_cells, d_cells_v, (const int*)grid.d_cube_id, grid.offsets(), grid.grid_size,

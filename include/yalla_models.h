@@ -32,6 +32,11 @@ typedef struct ya_sim ya_sim;
 
 /* 1 = HIP engine, 0 = CPU oracle. */
 int ya_models_is_device(void);
+/* Arithmetic tier of this build: 0 = exact (every statement in IEEE binary32 as written, no
+ * contraction, correctly rounded sqrt and reciprocal: bit-comparable with the oracle), 1 = fast
+ * (libyalla_models_fast.so: -DYA_ARITH_FAST -ffp-contract=fast, see include/solvers.cuh
+ * ya::exact_sqrt; within 1e-5 relative of the exact tier, not bit-identical). */
+int ya_models_arith(void);
 /* Number of models and their names ("springs_grid", "clipped_tile", ...). */
 int ya_models_count(void);
 const char* ya_models_name(int index);

@@ -10,6 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEVICE_LIB = os.path.join(_HERE, "libyalla_models.so")
+DEVICE_LIB_FAST = os.path.join(_HERE, "libyalla_models_fast.so")  # the fast-arithmetic tier
 CORE_LIB = os.path.join(_HERE, "libyalla_hip.so")
 
 _pf = C.POINTER(C.c_float)
@@ -19,6 +20,7 @@ _sim = C.c_void_p
 # name -> (restype, argtypes); mirrors include/yalla_models.h one to one.
 MODELS_ABI = {
     "ya_models_is_device": (C.c_int, []),
+    "ya_models_arith": (C.c_int, []),
     "ya_models_count": (C.c_int, []),
     "ya_models_name": (C.c_char_p, [C.c_int]),
     "ya_sim_create": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_float, C.POINTER(_sim)]),
@@ -95,14 +97,19 @@ def bind(path):
     return lib
 
 
-_device = None
+_device = {}
 
 
-def device_lib():
-    """The HIP engine.  Raises if the extension has not been built."""
-    global _device
-    if _device is None:
-        _device = bind(DEVICE_LIB)
-        if _device.ya_models_is_device() != 1:
-            raise RuntimeError(f"{DEVICE_LIB} is not the HIP build")
-    return _device
+def device_lib(arith="exact"):
+    """The HIP engine.  Raises if the extension has not been built.  arith "exact" (default:
+    bit-comparable with the oracle) or "fast" (libyalla_models_fast.so: contracted multiply-adds,
+    bare v_sqrt_f32 / v_rcp_f32; within 1e-5 relative of the exact tier)."""
+    if arith not in ("exact", "fast"):
+        raise ValueError("arith must be 'exact' or 'fast'")
+    if arith not in _device:
+        path = DEVICE_LIB if arith == "exact" else DEVICE_LIB_FAST
+        lib = bind(path)
+        if lib.ya_models_is_device() != 1 or lib.ya_models_arith() != (arith == "fast"):
+            raise RuntimeError(f"{path} is not the {arith}-arithmetic HIP build")
+        _device[arith] = lib
+    return _device[arith]
