@@ -68,11 +68,26 @@ MODELS = {
                        "Solution<Cell, Grid_solver>::take_step<relu_force> (examples/branching.cu point type)"),
     "springs_tile": (3, "ya::tile_force<float3, spring, friction_w_neighbour>",
                      "Solution<float3, Tile_solver>::take_step<spring> (examples/springs.cu)"),
+    # BASELINE configs 4 and 3 at their stated sizes (yalla_amd/cases.py grows / sets them up, or
+    # --state loads a saved system); division frozen during the timed steps
+    "passive_growth_grid": (5, "ya::grid_force_bits<Po_cell, relu_w_epithelium, friction_w_neighbour>",
+                            "Solution<Po_cell, Grid_solver>::take_step<relu_w_epithelium> + reset_nbs "
+                            "(examples/passive_growth.cu grown from 200 cells)"),
+    "branching_grid": (7, "ya::grid_force_bits<Cell, epi_turing_mes_noturing, friction_w_neighbour>",
+                       "Solution<Cell, Grid_solver>::take_step<epi_turing_mes_noturing> + reset_nbs "
+                       "(examples/branching.cu, 7-float cells)"),
 }
+STATE_MODELS = ("passive_growth_grid", "branching_grid")
 
 
-def force_kernel_label(default_name, variant, n):
+STATELESS_MODELS = ("springs_grid", "clipped_grid", "sorting_grid", "relu_grid", "relu_po_grid", "relu_cell_grid",
+                    "branching_grid", "springs_links_grid")   # YA_STATELESS in yalla_amd/csrc/model_functors.h
+
+
+def force_kernel_label(default_name, variant, n, model=""):
     """The force kernel a launch of n cells goes to (Grid_computer::forces, ya::coop::lanes_for)."""
+    if variant < 0:
+        variant = 3 if model in STATELESS_MODELS else 2
     if variant == 2 or "grid_force_bits" not in default_name:
         return default_name
     if variant == 3:
@@ -119,14 +134,17 @@ def parse(argv=None):
                          "(the base of the strong-scaling curve)")
     ap.add_argument("--model", default="springs_grid",
                     help="named model of the harness (default: the headline springs_grid)")
-    ap.add_argument("--dt", type=float, default=0.001)
+    ap.add_argument("--dt", type=float, default=None, help="default: 0.001 (springs), the model's own 0.2 for configs 3 / 4")
+    ap.add_argument("--state", default="", help="configs 3 / 4: .npz written by tools/make_state.py instead of setting "
+                                                "the system up here (rocprofv3 runs then see the steady state only)")
     ap.add_argument("--migrate-every", type=int, default=16,
                     help="slab path: hand over cells that left their slab every this many steps")
     ap.add_argument("--slab", action="store_true",
                     help="use the z-slab path (ghost exchange + all-reduce) even on 1 GPU")
-    ap.add_argument("--force-variant", type=int, default=2,
-                    help="2 = grid_force_bits (default), 1 = grid_force (byte FIFO), 0 = grid_force_direct (A/B), "
-                         "3 = grid_force_coop (opt-in: 16 lanes per cell, for <= ~5e4 cells)")
+    ap.add_argument("--force-variant", type=int, default=-1,
+                    help="-1 = the engine's choice (default: grid_force_bits, or grid_force_coop below ~1.5e5 cells "
+                         "when the model declared its functors stateless), 2 = grid_force_bits always, "
+                         "1 = grid_force (byte FIFO), 0 = grid_force_direct (A/B), 3 = grid_force_coop")
     ap.add_argument("--arith", default="exact", choices=["exact", "fast"],
                     help="arithmetic tier: exact (default; libyalla_models.so: IEEE binary32 statement by "
                          "statement, bit-comparable with the oracle) or fast (libyalla_models_fast.so: "
@@ -170,26 +188,43 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
+def counters_key(args, n_total):
+    """Key of this workload in profiles/r03_counters.json (None: no counters kept for it)."""
+    if args.slab or args.gpus > 1 or args.force_variant not in (-1, 2):
+        return None
+    tier = "" if args.arith == "exact" else "_fast"
+    if args.model == "springs_grid" and args.dist == 0.5 and n_total in (1_000_000, 10_000_000):
+        return ("springs_1M" if n_total == 1_000_000 else "springs_10M") + tier
+    if args.model == "sorting_grid" and n_total == 10_000:
+        return "cfg2_sorting_10k" + tier
+    if args.model == "branching_grid":
+        return "cfg3_branching_100k" + tier
+    if args.model == "passive_growth_grid":
+        return "cfg4_passive_growth_1M" + tier
+    return None
+
+
 def measured_counters(kernel_key):
     """Per-launch PMC figures of the dominant kernel from the committed rocprofv3 passes of
-    this same command (profiles/r02_counters.json, written by tools/roofline_json.py):
+    this same command (profiles/r03_counters.json, written by tools/roofline_json.py):
     HBM-side traffic (FETCH_SIZE and WRITE_SIZE from separate --pmc passes, KiB, FETCH_SIZE
     doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950) and the
     ceilings that bind this kernel.  Returns ({}, None) when there is no record."""
-    path = os.path.join(ROOT, "profiles", "r02_counters.json")
+    path = os.path.join(ROOT, "profiles", "r03_counters.json")
     try:
         with open(path) as f:
             rec = json.load(f)[kernel_key]
-    except (OSError, KeyError, ValueError):
+    except (OSError, KeyError, ValueError, TypeError):
         return {}, None
-    out = {k: rec.get(k) for k in ("valu_issue_frac", "valu_rate_frac", "lanes_active_frac", "lds_conflict_frac",
+    out = {k: rec.get(k) for k in ("valu_issue_frac", "lanes_active_frac", "fp32_lane_util", "valu_ns_per_inst",
+                                   "valu_rate_frac", "valu_rate_probe", "clock_ghz", "lds_conflict_frac",
                                    "lds_busy_frac", "wait_frac", "valu_insts_per_wave")}
     out["traffic"] = (2 * rec["FETCH_SIZE_KiB"] + rec["WRITE_SIZE_KiB"]) * 1024.0
     head = {"commit": rec.get("head"), "kernel_sha": rec.get("kernel_sha")}
     if rec.get("kernel_sha") != kernel_source_sha():
         # measured on an older kernel: do not pass the numbers off as this build's
-        sys.stderr.write("bench.py: profiles/r02_counters.json was measured on another kernel source "
-                         f"({rec.get('kernel_sha')} != {kernel_source_sha()}); traffic and PMC fractions omitted\n")
+        sys.stderr.write("bench.py: profiles/r03_counters.json[%s] was measured on another kernel source "
+                         "(%s != %s); traffic and PMC fractions omitted\n" % (kernel_key, rec.get("kernel_sha"), kernel_source_sha()))
         return {"stale_counters": True}, head
     return out, head
 
@@ -202,16 +237,17 @@ def grid_size_for(n, dist):
     return max(gs, 8)
 
 
-def cpu_baseline(model, n, gs, dist, dt, steps):
+def cpu_baseline(model, n, gs, dist, dt, steps, state=None):
     """The oracle (oracle/, a plain C++ port of the reference's algorithm, one
     thread) timed on the same workload: `steps` take_steps of the same system."""
-    from yalla_amd import _ffi
+    from yalla_amd import _ffi, cases
     from yalla_amd.solution import Solution
 
     path = os.path.join(ROOT, "oracle", "_build", "liboracle_models.so")
     lib = _ffi.bind(path)
-    with Solution(model, n, gs, 1.0, lib=lib) as s:
-        s.random_sphere(dist, 42)
+    with (cases.from_state(state, lib) if state is not None else Solution(model, n, gs, 1.0, lib=lib)) as s:
+        if state is None:
+            s.random_sphere(dist, 42)
         if model.startswith("sorting"):
             s.set_param("n_cells", n)
         t0 = time.perf_counter()
@@ -332,7 +368,19 @@ def main(argv=None):
 
     n_total = args.cells_total or args.cells or (1_000_000 if world == 1 else MULTI_GPU_CELLS)
     gs = args.grid_size or grid_size_for(n_total, args.dist)
-    dt = args.dt
+    dt = args.dt if args.dt is not None else (0.2 if args.model in STATE_MODELS else 0.001)
+    state = None
+    if args.model in STATE_MODELS:
+        # configs 4 / 3: the system at its stated size, set up (grown) here or loaded
+        from yalla_amd import cases
+        if args.state:
+            state = cases.load_state(args.state)
+            assert str(state["model"]) == args.model, "the saved state is another model's"
+        elif args.model == "passive_growth_grid":
+            state = cases.config4_state(engine, args.cells_total or args.cells or 1_000_000)
+        else:
+            state = cases.config3_state(engine, args.cells_total or args.cells or 100_000)
+        n_total, gs = int(state["n"]), int(state["grid_size"])
 
     native_comm = None
     if native_rccl:
@@ -361,8 +409,11 @@ def main(argv=None):
         return float(t.item())
 
     if not slab_path:
-        sim = Solution(args.model, n_total, gs, 1.0)
-        sim.random_sphere(args.dist, 42)
+        if state is not None:
+            sim = cases.from_state(state, engine)
+        else:
+            sim = Solution(args.model, n_total, gs, 1.0)
+            sim.random_sphere(args.dist, 42)
         if "grid" in args.model:
             sim.set_param("force_variant", args.force_variant)
             sim.set_param("sorted_pipeline", args.sorted_pipeline)
@@ -479,9 +530,8 @@ def main(argv=None):
         force_s = force_ms / 1e3 / max(launches, 1)
         force_bytes = force_bytes_per_cell(n_floats)
         achieved = n_force * force_bytes / force_s / 1e9 if launches else None
-        headline = (world == 1 and not args.slab and args.model == "springs_grid" and n_total == 1_000_000
-                    and args.dist == 0.5 and args.force_variant == 2 and args.arith == "exact")
-        counters, counters_head = measured_counters("grid_force_1M_springs") if headline else ({}, None)
+        key = counters_key(args, n_total)
+        counters, counters_head = measured_counters(key) if key else ({}, None)
         gather_bytes = gather_model_bytes_per_cell_update(n_floats, args.dist)
         out = {
             "metric": "cell-updates/sec at 1M cells (Grid_solver)",
@@ -500,7 +550,9 @@ def main(argv=None):
                             "strong scaling of one %d-cell system; base = one_gpu_same_system, not the N = 1 line" % n_total,
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic: random_sphere(%g) seed 42, glibc rand()" % args.dist,
+            "data": ("synthetic: random_sphere(%g) seed 42, glibc rand()" % args.dist) if state is None else
+                    ("synthetic: the model's own set-up (yalla_amd/cases.py)" +
+                     (", grown from 200 cells in %d steps" % int(state["growth_steps"]) if int(state["growth_steps"]) else "")),
             "config": {
                 "workload": f"{workload}, dt {dt:g}",
                 "model": args.model,
@@ -522,7 +574,7 @@ def main(argv=None):
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": force_kernel_label(kernel_name, args.force_variant, n_total // world),
+                "kernel": force_kernel_label(kernel_name, args.force_variant, n_total // world, args.model),
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -538,10 +590,18 @@ def main(argv=None):
                 # kernel structure requests (served here from LDS, not from HBM)
                 "gather_model_GBs": gather_bytes * value / world / 1e9,
                 "gather_model_bytes_per_cell_update": gather_bytes,
-                # the ceilings that do bind this kernel (PMC passes under profiles/, same command)
-                "valu_issue_frac": counters.get("valu_issue_frac"),   # at the ideal 2 cycles per wave64 VALU
-                "valu_rate_frac": counters.get("valu_rate_frac"),     # at the chip's measured sustained rate
+                # the ceilings that do bind this kernel (PMC passes under profiles/, same command):
+                # valu_issue_frac at the ideal 2 cycles per wave64 VALU; fp32_lane_util = that times the
+                # share of lanes active; valu_rate_frac against the rate tools/micro/valu_probe.hip
+                # measured in shader cycles (valu_rate_probe holds it with the clock the chip ran at)
+                "counters_key": key,
+                "valu_issue_frac": counters.get("valu_issue_frac"),
                 "lanes_active_frac": counters.get("lanes_active_frac"),
+                "fp32_lane_util": counters.get("fp32_lane_util"),
+                "valu_ns_per_inst": counters.get("valu_ns_per_inst"),
+                "valu_rate_frac": counters.get("valu_rate_frac"),
+                "valu_rate_probe": counters.get("valu_rate_probe"),
+                "kernel_clock_ghz": counters.get("clock_ghz"),
                 "lds_conflict_frac": counters.get("lds_conflict_frac"),
                 "lds_busy_frac": counters.get("lds_busy_frac"),
                 "wait_frac": counters.get("wait_frac"),
@@ -555,7 +615,7 @@ def main(argv=None):
         if counters.get("stale_counters"):
             out["roofline"]["stale_counters"] = True
         if world == 1 and not args.slab and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.model, n_total, gs, args.dist, dt, args.cpu_steps)
+            out["cpu_baseline"] = cpu_baseline(args.model, n_total, gs, args.dist, dt, args.cpu_steps, state)
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)

@@ -143,11 +143,11 @@ public:
     {
         if (int* l = lanes(solver, 0)) {
             saved_lanes = *l;
-            if (*l == 1) *l = 64;
+            if (*l <= 1) *l = 64;
         }
         if (int* v = variant(solver, 0)) {
             saved_variant = *v;
-            if (*v == 2) *v = 3;
+            if (*v == 2 || *v < 0) *v = 3;
         }
     }
     ~Cooperative_kernels()

@@ -44,6 +44,7 @@
 #include <string.h>
 
 #include <functional>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -93,6 +94,51 @@ using Generic_forces =
 template<typename Pt>
 void no_gen_forces(const int n, const Pt* __restrict__ d_X, Pt* d_dX)
 {}
+
+
+// ---- stateless functors ----------------------------------------------------------------------
+// One thread owns one cell for a whole stage because a functor may keep per-cell state without
+// atomics (`d_mes_nbs[i] += 1`, examples/passive_growth.cu:48-51).  Most functors do not: they are
+// pure functions of their arguments, or count with atomicAdd (examples/branching.cu:105-107).
+// A model says so with ONE line next to the functor,
+//
+//     __device__ float3 my_force(float3 Xi, float3 r, float dist, int i, int j) { ... }
+//     YA_STATELESS(float3, my_force)
+//
+// and the solvers then pick the kernels that share a cell among several lanes whenever the
+// system is too small to fill the chip with one lane per cell (ya::tile_force_coop,
+// ya::grid_force_coop: 2-8 x faster steps below ~10^5 cells, bit-identical results: every sum is
+// still accumulated in the reference's order).  Custom friction functors take
+// YA_STATELESS_FRICTION; the two defaults are known to be stateless.
+namespace ya {
+template<typename Pt, Pairwise_interaction<Pt> pw_int>
+struct Stateless_interaction : std::false_type {};
+template<typename Pt, Pairwise_friction<Pt> pw_friction>
+struct Stateless_friction : std::false_type {};
+// the two default frictions, for any point type (compared as template arguments: class scope,
+// where naming a __device__ function is allowed on the host side too)
+template<typename Pt, Pairwise_friction<Pt> pw_friction>
+struct Default_friction {
+    static constexpr bool value =
+        pw_friction == &friction_w_neighbour<Pt> || pw_friction == &friction_on_background<Pt>;
+};
+template<typename Pt, Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction>
+constexpr bool stateless_pair()
+{
+    return Stateless_interaction<Pt, pw_int>::value &&
+           (Default_friction<Pt, pw_friction>::value || Stateless_friction<Pt, pw_friction>::value);
+}
+}  // namespace ya
+#define YA_STATELESS(Pt_, functor_)                                            \
+    namespace ya {                                                            \
+    template<>                                                                \
+    struct Stateless_interaction<Pt_, functor_> : std::true_type {};          \
+    }
+#define YA_STATELESS_FRICTION(Pt_, functor_)                                   \
+    namespace ya {                                                            \
+    template<>                                                                \
+    struct Stateless_friction<Pt_, functor_> : std::true_type {};             \
+    }
 
 
 namespace ya {
@@ -885,8 +931,28 @@ namespace bits {
 #define YA_MASK_WORDS 4
 #endif
 #ifndef YA_BITS_POPS
-#define YA_BITS_POPS 2  /* hits popped per trip of phase 2 (1 or 2) */
+#define YA_BITS_POPS 2  /* hits popped per trip of phase 2 (1 or 2), three-float points */
 #endif
+#ifndef YA_BITS_POPS_WIDE
+#define YA_BITS_POPS_WIDE 2  /* the same for wider points (A/B knob: one pop per trip saves 10 VGPRs of config */
+#endif                       /* 4's 146 and is 3 % slower there: two hits' memory accesses in flight matter more) */
+// Wavefronts per SIMD the register allocator must leave room for (A/B knob).  Default 1 = the
+// compiler's own choice.  Measured on config 4 (1.16 M Po_cell, relu_w_epithelium: 146 VGPRs, three
+// wavefronts per SIMD, 78 % of wave cycles at s_waitcnt): forcing four (128 VGPRs + 8 spilled)
+// made the launch SLOWER, 1431 -> 1615 us -- that kernel is bound by the address path of the
+// functor's own global accesses (d_type[i], d_type[j], d_mes_nbs[i] += 1 by original id: 64 cache
+// lines per wavefront instruction, TA 73 % busy), and more wavefronts only queue there.
+#ifndef YA_BITS_MIN_WAVES_WIDE
+#define YA_BITS_MIN_WAVES_WIDE 1
+#endif
+template<typename Pt>
+struct Min_waves {
+    static constexpr int value = sizeof(Pt) <= 16 ? 1 : YA_BITS_MIN_WAVES_WIDE;
+};
+template<typename Pt>
+struct Pops {
+    static constexpr int value = sizeof(Pt) <= 16 ? YA_BITS_POPS : YA_BITS_POPS_WIDE;
+};
 constexpr int BLOCK = YA_BITS_BLOCK;
 constexpr int WORDS = YA_MASK_WORDS;
 constexpr int PASS_BITS = 32 * WORDS;
@@ -897,7 +963,11 @@ struct Stage {
 #ifndef YA_BITS_STAGE_CELLS
 #define YA_BITS_STAGE_CELLS (3 * YA_BITS_BLOCK + 160)
 #endif
-    static constexpr int value = sizeof(Entry<Pt>) <= 32 ? YA_BITS_STAGE_CELLS : YA_BITS_STAGE_CELLS / 2;
+    // 16- and 24-byte entries: 352 cells (7 / 9.7 KiB per wavefront with the masks: 5 / 4 wavefronts
+    // per SIMD); 32-byte entries (7-float points): 256 cells = 9.5 KiB, so that a fourth wavefront
+    // fits the CU's LDS (352 were 12.6 KiB: three) -- denser planes are staged in chunks
+    static constexpr int value = sizeof(Entry<Pt>) <= 24 ? YA_BITS_STAGE_CELLS
+                                 : (sizeof(Entry<Pt>) <= 32 ? 256 : YA_BITS_STAGE_CELLS / 2);
 };
 
 // m = 2 m + (d2 < cut2)
@@ -920,6 +990,7 @@ __device__ __forceinline__ void pass(const Entry<Pt>* __restrict__ sh_e, const f
     const Pt& Xi, const int i, const float cut2, Pt& F, float3& sum_v, float& sum_friction,
     const int* __restrict__ global_id)
 {
+    constexpr int POPS = Pops<Pt>::value;
     // ---- phase 1 ----
     unsigned m = 0;
     int p = 0;  // bits emitted
@@ -990,14 +1061,14 @@ __device__ __forceinline__ void pass(const Entry<Pt>* __restrict__ sh_e, const f
         left -= refill ? 1 : 0;
         nxt = *rp;
         if (cur != 0) {
-            // up to YA_BITS_POPS hits of the word: the loads of the later ones are issued before
+            // up to POPS hits of the word: the loads of the later ones are issued before
             // the first one's arithmetic (a hit that is not there repeats the one before it)
-            int pos[YA_BITS_POPS];
-            bool have[YA_BITS_POPS];
-            Entry<Pt> other[YA_BITS_POPS];
-            float4 v[YA_BITS_POPS];
+            int pos[POPS];
+            bool have[POPS];
+            Entry<Pt> other[POPS];
+            float4 v[POPS];
 #pragma unroll
-            for (int u = 0; u < YA_BITS_POPS; u++) {
+            for (int u = 0; u < POPS; u++) {
                 have[u] = cur != 0;
                 pos[u] = have[u] ? __builtin_clz(cur) : pos[u > 0 ? u - 1 : 0];
                 cur = have[u] ? cur & (0x7fffffffu >> pos[u]) : cur;
@@ -1005,7 +1076,7 @@ __device__ __forceinline__ void pass(const Entry<Pt>* __restrict__ sh_e, const f
             }
             YA_BITS_PAIR(other[0], v[0])
 #pragma unroll
-            for (int u = 1; u < YA_BITS_POPS; u++)
+            for (int u = 1; u < POPS; u++)
                 if (have[u]) YA_BITS_PAIR(other[u], v[u])
         }
     }
@@ -1018,7 +1089,7 @@ __device__ __forceinline__ void pass(const Entry<Pt>* __restrict__ sh_e, const f
 // rather than a null test so that the single-GPU kernel carries neither the test nor the gather.
 template<typename Pt, Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction, bool STAGE_V = false,
     bool GLOBAL_IDS = false>
-__global__ __launch_bounds__(bits::BLOCK) void grid_force_bits(const int n,
+__global__ __launch_bounds__(bits::BLOCK, bits::Min_waves<Pt>::value) void grid_force_bits(const int n,
     const Entry<Pt>* __restrict__ sorted, const float4* __restrict__ sorted_v,
     const int* __restrict__ cube_id, const int* __restrict__ offs, const int gs,
     const int n_cubes, const float cut2, Pt* __restrict__ d_dX, const bool has_gen,
@@ -1987,11 +2058,12 @@ public:
     Tile_computer(int n_max) {}
     ya::Profiler profiler;
     bool use_sorted_pipeline() const { return false; }
-    // 1 (default) = one thread owns a cell for the whole stage, as in the reference; 16 or 64 =
-    // ya::tile_force_coop with that many lanes per cell (bit-identical sums; force launch at 800
-    // cells 196 -> 32 us with 64 lanes, at 3000 cells 631 -> 135 us with 16), for functors that
-    // keep no per-cell state non-atomically.
-    int lanes_per_cell = 1;
+    // 0 (default) = one thread owns a cell for the whole stage, as in the reference, unless the
+    // functors are declared stateless (YA_STATELESS): then 64 lanes per cell up to 4096 cells and
+    // 16 above; 1 = always one thread per cell; 16 or 64 = ya::tile_force_coop with that many
+    // lanes per cell whatever the functor says (bit-identical sums; force launch at 800 cells
+    // 196 -> 32 us with 64 lanes, at 3000 cells 631 -> 135 us with 16).
+    int lanes_per_cell = 0;
 
 protected:
     hipStream_t stream = nullptr;  // every launch of a step goes here (null = the default stream)
@@ -2011,10 +2083,12 @@ protected:
         assert(n_active == n);  // Tile_solver is single-GPU only (all pairs)
         hipEvent_t start, stop;
         profiler.next(&start, &stop);
-        if (lanes_per_cell >= 64)
+        int lanes = lanes_per_cell;
+        if (lanes == 0) lanes = ya::stateless_pair<Pt, pw_int, pw_friction>() ? (n <= 4096 ? 64 : 16) : 1;
+        if (lanes >= 64)
             hipExtLaunchKernelGGL((ya::tile_force_coop<Pt, pw_int, pw_friction, 64>), dim3((n + 3) / 4),
                 dim3(256), 0, stream, start, stop, 0, n, d_X, d_old_v, d_dX, has_gen);
-        else if (lanes_per_cell > 1)
+        else if (lanes > 1)
             hipExtLaunchKernelGGL((ya::tile_force_coop<Pt, pw_int, pw_friction, 16>), dim3((n + 15) / 16),
                 dim3(256), 0, stream, start, stop, 0, n, d_X, d_old_v, d_dX, has_gen);
         else
@@ -2122,11 +2196,13 @@ class Grid_computer {
 public:
     float cube_size;
     ya::Profiler profiler;
-    // 2 = grid_force_bits (bit stream, default), 1 = grid_force (byte FIFO), 0 = grid_force_direct (A/B);
+    // 2 = grid_force_bits (bit stream) always, 1 = grid_force (byte FIFO), 0 = grid_force_direct (A/B);
     // 3 = grid_force_coop below ~1.5 * 10^5 cells (16, 8 or 4 lanes per cell, more the smaller the
     // system), grid_force_bits above: for models whose functors keep no per-cell state without
     // atomics (bit-identical results; see the kernel's comment)
-    int force_variant = 2;
+    // -1 (default) = grid_force_bits, or -- for functors declared stateless (YA_STATELESS) --
+    // grid_force_coop below ~1.5 * 10^5 cells
+    int force_variant = -1;
     int coop_lanes = 0;            // force_variant 3: 0 = from n (ya::coop::lanes_for), or 4 / 8 / 16
     int stage_v_max = 130000;      // grid_force_bits keeps old_v in LDS too up to this many cells
     Grid_computer(int n_max, int grid_size = 50, float cube_size = 1)
@@ -2188,6 +2264,9 @@ protected:
             __VA_ARGS__);                                                                     \
     else                                                                                      \
         hipLaunchKernelGGL((kernel_), dim3(grid_), dim3(block_), 0, stream, __VA_ARGS__)
+        // the kernel this launch goes to: an explicit choice, or by what the model said about its functors
+        const int force_variant = this->force_variant >= 0 ? this->force_variant
+                                  : (ya::stateless_pair<Pt, pw_int, pw_friction>() ? 3 : 2);
         const int lanes = force_variant == 3 ? (coop_lanes ? coop_lanes : ya::coop::lanes_for(n)) : 1;
 #define YA_COOP_LAUNCH(lanes_)                                                                 \
     YA_FORCE_LAUNCH((ya::grid_force_coop<Pt, pw_int, pw_friction, lanes_>),                    \

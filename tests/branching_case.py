@@ -1,49 +1,5 @@
 """BASELINE config 3 (examples/branching.cu) as a reusable test case: a 7-float
 Cell {x, y, z, theta, phi, u, v}, Turing kinetics in the self-interaction,
 diffusion + bending between epithelial cells, neighbour counters by atomicAdd,
-division before every step."""
-import numpy as np
-
-from yalla_amd.solution import Solution
-
-MESENCHYME, EPITHELIUM = 0, 1
-
-
-def setup(lib, n_0=500, n_max=4000, seed=9):
-    with Solution("relu_cell_grid", n_0, 100, 1.0, lib=lib) as relax:   # relaxed_sphere(0.75)
-        if lib.ya_models_is_device() == 0:
-            relax.set_reduce_order(1)
-        relax.random_sphere(0.6, seed)
-        relax.take_step(0.1, 300)
-        X0 = relax.positions()
-    s = Solution("branching_grid", n_max, 100, 1.0, lib=lib)            # branching.cu:176
-    if lib.ya_models_is_device() == 0:
-        s.set_reduce_order(1)
-    s.h_n = n_0
-    s.h_X[:] = 0
-    s.h_X[:n_0, :3] = X0[:, :3] * np.float32(0.75 / 0.8)
-    s.copy_to_device()
-    s.set_prop("type", np.zeros(n_max, np.int32))
-    # find the epithelium: branching.cu:231-250 (a step of dt = 0 just counts)
-    s.set_prop("mes_nbs", np.zeros(n_max, np.int32))
-    s.set_param("reset_nbs", 0)
-    s.take_step(0.0)
-    s.set_param("reset_nbs", 1)
-    s.copy_to_host()
-    nbs = s.get_prop("mes_nbs", n_0)
-    types = np.zeros(n_max, np.int32)
-    rng = np.random.default_rng(1)
-    X = s.h_X
-    for i in range(n_0):
-        if nbs[i] < 20:
-            types[i] = EPITHELIUM
-            dist = np.sqrt(np.float32(X[i, 0] * X[i, 0] + X[i, 1] * X[i, 1] + X[i, 2] * X[i, 2]))
-            X[i, 3] = np.arccos(np.float32(X[i, 2] / dist))
-            X[i, 4] = np.arctan2(X[i, 1], X[i, 0])
-            X[i, 5] = rng.random() / 5 - 0.1
-            X[i, 6] = rng.random() / 5 - 0.1
-    s.copy_to_device()
-    s.set_prop("type", types)
-    s.set_param("prolif_rate", 1.0)   # switches division on; the rule has its own rates
-    s.set_param("seed", 123)
-    return s, nbs
+division before every step.  The set-up itself lives in yalla_amd/cases.py."""
+from yalla_amd.cases import EPITHELIUM, MESENCHYME, branching_setup as setup  # noqa: F401

@@ -125,11 +125,11 @@ int main()
                 if (grid) {
                     Solution<float3, Grid_solver> p{n, 50, 1.f};
                     run(p);
-                    EXPECT(p.force_variant == 2);  // restored
+                    EXPECT(p.force_variant == -1);  // restored
                 } else {
                     Solution<float3, Tile_solver> p{n};
                     run(p);
-                    EXPECT(p.lanes_per_cell == 1);
+                    EXPECT(p.lanes_per_cell == 0);
                 }
             }
             int different = 0;

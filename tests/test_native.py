@@ -63,3 +63,11 @@ def test_link_forces_with_cell_ids_beyond_2_to_24():
     or equal the former dead key 0xFFFFFF: segmented-sum path (32 key bits) and atomics path
     against a host evaluation."""
     run("test_links_big_ids", "ALL BIG-ID LINK TESTS PASSED")
+
+
+@pytest.mark.gpu
+def test_one_line_declares_a_functor_stateless():
+    """YA_STATELESS(Pt, functor) next to a model's functor: Grid_solver at 10 000 cells and
+    Tile_solver at 800 pick the several-lanes-per-cell kernels by themselves -- bit-identical
+    positions, >= 1.4 x / 2 x faster steps, >= 1e8 cell-updates/s at BASELINE config 2's size."""
+    run("test_stateless", "ALL STATELESS TESTS PASSED")

@@ -1,15 +1,21 @@
 #!/bin/bash
-# Everything the profiles/ directory is made from, in one gpurun call:
-#   gpu_profile_round.sh <tag>
-# default bench (with cpu_baseline), rocprofv3 kernel stats of the same command, and the
-# PMC passes (traffic: FETCH_SIZE and WRITE_SIZE in separate passes; SQ / cache counters).
-tag=${1:-round}
+# Everything one entry of the profiles/ directory is made from, in one gpurun call:
+#   gpu_profile_round.sh <tag> [bench.py arguments ...]
+# the bench line (with cpu_baseline), rocprofv3 kernel stats of the same command, and the PMC
+# passes (traffic: FETCH_SIZE and WRITE_SIZE in separate passes; SQ / cache counters).
+# Afterwards, here: python tools/roofline_json.py gpurun_out/<tag> profiles/r03_counters.json <key> "<args>"
+tag=${1:-round}; shift
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag; mkdir -p $out
 cd $GRAFT_REPO_ROOT
-timeout 600 python bench.py > $out/bench.json 2> $out/bench.err
+state=""
+case " $* " in
+  *" passive_growth_grid "*) timeout 600 python tools/make_state.py 4 /tmp/state.npz > $out/state.log 2>&1; state="--state /tmp/state.npz";;
+  *" branching_grid "*) timeout 600 python tools/make_state.py 3 /tmp/state.npz > $out/state.log 2>&1; state="--state /tmp/state.npz";;
+esac
+timeout 900 python bench.py "$@" $state > $out/bench.json 2> $out/bench.err
 cat $out/bench.json
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o k -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $out/stats_bench.json 2> $out/stats.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o k -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline "$@" $state > $out/stats_bench.json 2> $out/stats.err
 i=0
 for pass in "FETCH_SIZE" "WRITE_SIZE" \
   "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS" \
@@ -18,7 +24,9 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" \
   "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum" \
   "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $out/pmc$i -o p -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 10 --warmup 2 > $out/pmc$i.json 2> $out/pmc$i.err
+  rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $out/pmc$i -o p -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 10 --warmup 2 "$@" $state > $out/pmc$i.json 2> $out/pmc$i.err
 done
 python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py "$out/pmc*/*counter_collection.csv" > $out/pmc_summary.txt
+# keep what is judged small: the per-kernel stats and the counter files of the force kernel only
+for d in $out/pmc*; do rm -f $d/*agent_info.csv; done
 ls $out

@@ -1,0 +1,5 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+bash tools/gpu_profile_round.sh r03_cfg4 --model passive_growth_grid --cpu-steps 3 2>&1 | tail -3
+bash tools/gpu_profile_round.sh r03_cfg3 --model branching_grid --cpu-steps 20 2>&1 | tail -3
+bash tools/gpu_profile_round.sh r03_cfg2 --model sorting_grid --cells-total 10000 --dt 0.05 --steps 300 --cpu-steps 300 2>&1 | tail -3

@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-DEVICE_LIB = os.path.join(_HERE, "libyalla_models.so")
+# YALLA_MODELS_LIB: another build of the same library (A/B of build flags, tools/gpu_*.sh)
+DEVICE_LIB = os.environ.get("YALLA_MODELS_LIB") or os.path.join(_HERE, "libyalla_models.so")
 DEVICE_LIB_FAST = os.path.join(_HERE, "libyalla_models_fast.so")  # the fast-arithmetic tier
 CORE_LIB = os.path.join(_HERE, "libyalla_hip.so")
 

@@ -403,3 +403,16 @@ inline void proliferate(float rate, double mean_dist, unsigned seed, unsigned st
 #endif
 
 }  // namespace models
+
+// What the models say about their functors (include/solvers.cuh, YA_STATELESS; nothing on the
+// oracle): pure functions of their arguments, or counting with atomicAdd (branching.cu:105-107).
+// relu_w_epithelium is NOT listed: it counts with `d_mes_nbs[i] += 1` (passive_growth.cu:48-51).
+#ifdef YA_STATELESS
+YA_STATELESS(float3, models::spring)
+YA_STATELESS(float3, models::clipped_spring)
+YA_STATELESS(float3, models::differential_adhesion)
+YA_STATELESS(float3, relu_force<float3>)
+YA_STATELESS(Po_cell, relu_force<Po_cell>)
+YA_STATELESS(Cell, relu_force<Cell>)
+YA_STATELESS(Cell, models::epi_turing_mes_noturing)
+#endif
