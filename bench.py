@@ -137,8 +137,9 @@ def parse(argv=None):
     ap.add_argument("--dt", type=float, default=None, help="default: 0.001 (springs), the model's own 0.2 for configs 3 / 4")
     ap.add_argument("--state", default="", help="configs 3 / 4: .npz written by tools/make_state.py instead of setting "
                                                 "the system up here (rocprofv3 runs then see the steady state only)")
-    ap.add_argument("--migrate-every", type=int, default=16,
-                    help="slab path: hand over cells that left their slab every this many steps")
+    ap.add_argument("--migrate-every", type=int, default=8,
+                    help="slab path: hand over cells that left their slab (and re-select the mirrored cells) every "
+                         "this many steps; cells must not drift further than an eighth of a cube in between")
     ap.add_argument("--slab", action="store_true",
                     help="use the z-slab path (ghost exchange + all-reduce) even on 1 GPU")
     ap.add_argument("--force-variant", type=int, default=-1,
@@ -153,10 +154,6 @@ def parse(argv=None):
                     help="torch.distributed backend for N > 1 / --slab: nccl (= RCCL), or gloo with "
                          "YALLA_BENCH_DEVICE=0 to rehearse the N-rank path on one GPU (RCCL refuses "
                          "two ranks per GPU; messages are then staged through the host)")
-    ap.add_argument("--sequencing", default="native", choices=["native", "python"],
-                    help="z-slab path: the step sequenced in C++ (ya_slab_step; with --backend nccl the "
-                         "messages go through libyalla_hip.so's own RCCL communicator and torch.distributed "
-                         "is not used at all) or by yalla_amd/slab.py over torch.distributed (A/B)")
     ap.add_argument("--time-every", type=int, default=5,
                     help="attach HIP events to every this-many-th force-kernel launch (odd: both stages)")
     ap.add_argument("--sorted-pipeline", type=int, default=1,
@@ -345,7 +342,7 @@ def main(argv=None):
         sys.exit(f"bench.py: rank {rank} wants GPU {local_rank}, but only {torch.cuda.device_count()} "
                  "are visible (one process per GPU)")
     torch.cuda.set_device(local_rank)
-    native_rccl = slab_path and args.sequencing == "native" and args.backend == "nccl"
+    native_rccl = slab_path and args.backend == "nccl"
     use_torch_dist = slab_path and not native_rccl
     if use_torch_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -448,31 +445,23 @@ def main(argv=None):
         with Solution("springs_tile", n_total) as whole:
             whole.random_sphere(args.dist, 42)
             X0 = whole.h_X[:n_total].copy()
-        bounds = slab_mod.slab_bounds(X0[:, 2], world)
-        native_step = args.sequencing == "native"
-        my_slab = slab_mod.Slab("springs_grid", X0, rank, world, bounds, gs, cube_size=1.0, lib=engine,
-                                device=f"cuda:{local_rank}", python_buffers=not native_step,
+        my_slab = slab_mod.Slab("springs_grid", X0, rank, world, gs, cube_size=1.0, lib=engine,
                                 global_ids=False)  # spring only compares i with j
         del X0
         sim = my_slab.sim
         sim.set_param("force_variant", args.force_variant)
         if native_rccl:
-            my_slab.setup_native_step(comm=native_comm)
-        elif native_step:
-            my_slab.setup_native_step(transport=slab_mod.CallbackTransport(device_memory=True))
+            my_slab.use(comm=native_comm)
         else:
-            comm = slab_mod.DistComm()
+            my_slab.use(transport=slab_mod.CallbackTransport(device_memory=True))
 
         step_no = [0]
 
         def slab_step(migrate):
-            if native_step:
-                my_slab.step_native(dt, migrate)
-            else:
-                slab_mod.step([my_slab], comm, dt, migrate=migrate)
+            my_slab.step(dt, migrate)
 
         def advance(k):
-            # cells move ~1e-2 per step here; the ghost layer tolerates 0.25 of stray
+            # cells move ~1e-2 per step here; between migrations they may drift an eighth of a cube
             for _ in range(k):
                 step_no[0] += 1
                 slab_step(step_no[0] % args.migrate_every == 0)
@@ -565,11 +554,10 @@ def main(argv=None):
                 "arith": args.arith,
                 "links": n_links if not slab_path else 0,
                 "parallelism": "1 GPU" if world == 1 else
-                               f"{world} z-slabs of one {n_total}-cell system, step sequenced "
-                               + ("in C++ (ya_slab_step)" if args.sequencing == "native" else "by yalla_amd/slab.py")
-                               + ", ghost exchange via "
-                               + (("RCCL send/recv (libyalla_hip.so's communicator)" if native_rccl else
-                                   "RCCL send/recv (torch.distributed)") if args.backend == "nccl" else
+                               f"{world} z-slabs of one {n_total}-cell system, step sequenced in C++ (ya_slab_step: "
+                               "mirrored ghost cells, one message of right-hand sides per neighbour and stage beside the "
+                               "interior tiles' forces), messages via "
+                               + ("RCCL send/recv (libyalla_hip.so's communicator)" if native_rccl else
                                   f"{args.backend} send/recv staged through the host (rehearsal mode)"),
             },
             "roofline": {

@@ -1093,7 +1093,8 @@ __global__ __launch_bounds__(bits::BLOCK, bits::Min_waves<Pt>::value) void grid_
     const Entry<Pt>* __restrict__ sorted, const float4* __restrict__ sorted_v,
     const int* __restrict__ cube_id, const int* __restrict__ offs, const int gs,
     const int n_cubes, const float cut2, Pt* __restrict__ d_dX, const bool has_gen,
-    const int n_active, Pt* __restrict__ d_dX_sorted, const int* __restrict__ global_id)
+    const int n_active, Pt* __restrict__ d_dX_sorted, const int* __restrict__ global_id,
+    const int part = 0, const int part_cube_lo = 0, const int part_cube_hi = 0)
 {
     constexpr int FB = bits::BLOCK;
     constexpr int CAP = bits::Stage<Pt>::value;
@@ -1105,7 +1106,26 @@ __global__ __launch_bounds__(bits::BLOCK, bits::Min_waves<Pt>::value) void grid_
     __shared__ float4 sh_v[STAGE_V ? CAP + 8 : 1];
     bits::Lds_word* const words = (bits::Lds_word*)sh_m + threadIdx.x;
 
-    const int s0 = xcd_contiguous_tile(blockIdx.x, gridDim.x) * FB;
+    // z-slab decomposition: a stage's forces in two launches, so that the right-hand sides the
+    // slab neighbours wait for are computed and sent first.  part 1 = the tiles that hold the
+    // cells of the cubes below part_cube_lo or from part_cube_hi up (the z-planes next to the
+    // slab's faces: cube ids are z-major, so these are the two ends of the sorted array), part 2
+    // = the tiles in between, 0 = every tile.  Either launch spreads ITS tiles over all eight
+    // XCDs (a launch that kept the whole array's mapping would occupy only the XCDs that own its
+    // end of the array, and take as long as the full launch); blocks beyond its share exit.
+    int tile;
+    if (part == 0) {
+        tile = xcd_contiguous_tile(blockIdx.x, gridDim.x);
+    } else {
+        const int tiles = gridDim.x;
+        const int t_lo = min((offs[min(part_cube_lo, n_cubes)] + FB - 1) / FB, tiles);
+        const int t_hi = max(min(offs[min(part_cube_hi, n_cubes)] / FB, tiles), t_lo);
+        const int mine = part == 1 ? t_lo + (tiles - t_hi) : t_hi - t_lo;
+        if ((int)blockIdx.x >= mine) return;
+        const int t = xcd_contiguous_tile(blockIdx.x, mine);
+        tile = part == 1 ? (t < t_lo ? t : t_hi + (t - t_lo)) : t_lo + t;
+    }
+    const int s0 = tile * FB;
     const int s = s0 + threadIdx.x;
     bool active = s < n;
     const int c_lo = cube_id[s0];
@@ -1930,14 +1950,16 @@ protected:
             stage == 1 ? d_dX : d_dX1, n_floats, n, d_mean, d_workspace, nullptr));
         return d_mean;
     }
-    void stage_update(int stage, int n, float dt, const float* d_fix_velocity)
+    // n_sorted_active: the cells moved inside the cube-sorted copy by their sorted right-hand
+    // sides (a z-slab moves its own cells there; mirrored cells enter the copy from d_X1)
+    void stage_update(int stage, int n, float dt, const float* d_fix_velocity, int n_sorted_active = -1)
     {
         const int blocks = (n + ya::UPDATE_BLOCK - 1) / ya::UPDATE_BLOCK;
         if (stage == 1) {
             // before euler_step: it replaces d_dX by d_dX - fix, the sorted copy is raw
             if (sorted_stage_cells >= 0)
                 Computer<Pt>::predictor_in_sorted_space(
-                    sorted_stage_cells, dt, d_fix_velocity, n);
+                    sorted_stage_cells, dt, d_fix_velocity, n_sorted_active >= 0 ? n_sorted_active : n);
             euler_step<<<blocks, ya::UPDATE_BLOCK>>>(n, dt, d_X, d_fix_velocity, d_dX, d_X1);
         } else
             heun_step<<<blocks, ya::UPDATE_BLOCK>>>(
@@ -2231,9 +2253,22 @@ public:
         ya_free(d_resorted);
         ya_free(d_resorted_v);
         ya_free(d_dX_sorted);
+        if (interior_stream) {
+            (void)hipStreamDestroy(interior_stream);
+            (void)hipEventDestroy(grid_built);
+            (void)hipEventDestroy(interior_done);
+        }
     }
     Grid_computer(const Grid_computer&) = delete;
     bool sorted_pipeline = true;  // false = both stages through d_X / d_X1 (A/B)
+    // z-slab decomposition (include/slab_logic.inc): 1 = the next forces() call launches the tiles
+    // in the z-planes next to the slab's faces only (cube ids below force_part_cube_lo or from
+    // force_part_cube_hi up) and remembers its arguments; forces_interior() then launches the
+    // rest on a stream of its own, and join_interior() makes the step's stream wait for it.  The
+    // exchange of the boundary cells' right-hand sides runs beside the interior launch.  Kernels
+    // other than grid_force_bits compute everything in the first call.
+    int force_part = 0;
+    int force_part_cube_lo = 0, force_part_cube_hi = 0x7fffffff;
     // z-slab decomposition: local cell index -> global id (own cells, then ghosts); pairwise
     // functors are then called with global (i, j).  NULL (default): local = global.
     const int* d_global_id = nullptr;
@@ -2248,6 +2283,33 @@ protected:
     float4 *d_sorted_v, *d_resorted_v;
     Pt* d_dX_sorted;
     void check_status() { grid.check_status(); }
+    struct Forces_call {
+        int n = 0, n_active = 0;
+        const ya::Entry<Pt>* d_cells = nullptr;
+        const float4* d_cells_v = nullptr;
+        Pt *d_dX = nullptr, *d_dX_in_cell_order = nullptr;
+        bool has_gen = false, split = false;
+    } boundary_call;
+    hipStream_t interior_stream = nullptr;
+    hipEvent_t grid_built = nullptr, interior_done = nullptr;
+    // the second launch of a stage whose first one ran with force_part = 1
+    template<Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction>
+    void forces_interior()
+    {
+        if (!boundary_call.split) return;  // the first call computed every tile
+        const Forces_call c = boundary_call;
+        const int part = force_part;
+        force_part = 2;
+        forces<pw_int, pw_friction>(c.n, c.d_cells, c.d_cells_v, c.d_dX, c.has_gen, c.n_active, c.d_dX_in_cell_order);
+        force_part = part;
+        YA_CHECK((int)hipEventRecord(interior_done, interior_stream));
+    }
+    void join_interior()
+    {
+        if (!boundary_call.split) return;
+        YA_CHECK((int)hipStreamWaitEvent(stream, interior_done, 0));
+        boundary_call.split = false;
+    }
     template<Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction>
     void forces(const int n, const ya::Entry<Pt>* d_cells, const float4* d_cells_v, Pt* d_dX,
         const bool has_gen, const int n_active, Pt* d_dX_in_cell_order)
@@ -2268,6 +2330,28 @@ protected:
         const int force_variant = this->force_variant >= 0 ? this->force_variant
                                   : (ya::stateless_pair<Pt, pw_int, pw_friction>() ? 3 : 2);
         const int lanes = force_variant == 3 ? (coop_lanes ? coop_lanes : ya::coop::lanes_for(n)) : 1;
+        // two launches per stage (force_part) are what grid_force_bits offers; the other kernels
+        // compute every tile in the first call
+        const bool bits_kernel = lanes == 1 && force_variant >= 2;
+        int part = 0;
+        hipStream_t stream = this->stream;
+        if (force_part == 1) {
+            boundary_call = Forces_call{n, n_active, d_cells, d_cells_v, d_dX, d_dX_in_cell_order, has_gen, bits_kernel};
+            if (bits_kernel) {
+                part = 1;
+                if (!interior_stream) {
+                    YA_CHECK((int)hipStreamCreateWithFlags(&interior_stream, hipStreamNonBlocking));
+                    YA_CHECK((int)hipEventCreateWithFlags(&grid_built, hipEventDisableTiming));
+                    YA_CHECK((int)hipEventCreateWithFlags(&interior_done, hipEventDisableTiming));
+                }
+                // the interior launch needs the grid, not the boundary launch
+                YA_CHECK((int)hipEventRecord(grid_built, stream));
+            }
+        } else if (force_part == 2) {
+            part = 2;
+            stream = interior_stream;
+            YA_CHECK((int)hipStreamWaitEvent(interior_stream, grid_built, 0));
+        }
 #define YA_COOP_LAUNCH(lanes_)                                                                 \
     YA_FORCE_LAUNCH((ya::grid_force_coop<Pt, pw_int, pw_friction, lanes_>),                    \
         (n + ya::coop::BLOCK / lanes_ - 1) / (ya::coop::BLOCK / lanes_), ya::coop::BLOCK, n,   \
@@ -2284,7 +2368,8 @@ protected:
     YA_FORCE_LAUNCH((ya::grid_force_bits<Pt, pw_int, pw_friction, stage_v_, gids_>),           \
         (n + ya::bits::BLOCK - 1) / ya::bits::BLOCK, ya::bits::BLOCK, n, d_cells, d_cells_v,   \
         (const int*)grid.d_cube_id, grid.offsets(), grid.grid_size, grid.n_cubes, cut2, d_dX,  \
-        has_gen, n_active, d_dX_in_cell_order, (const int*)d_global_id)
+        has_gen, n_active, d_dX_in_cell_order, (const int*)d_global_id, part, force_part_cube_lo, \
+        force_part_cube_hi)
             const bool stage_v = n <= stage_v_max;
             if (d_global_id) {
                 if (stage_v) {

@@ -211,6 +211,11 @@ int ya_comm_world(const ya_comm* comm);
  * (the first and last rank have one neighbour; their other buffers may be NULL). */
 int ya_comm_exchange(ya_comm* comm, const void* d_send_lo, void* d_recv_lo, const void* d_send_hi,
     void* d_recv_hi, size_t bytes, void* stream);
+/* The same with a size per message: what goes to a neighbour need not be as long as what comes
+ * from it (ghost rows travel at their exact length).  A size of 0 skips that message. */
+int ya_comm_exchange_v(ya_comm* comm, const void* d_send_lo, size_t send_lo_bytes, void* d_recv_lo,
+    size_t recv_lo_bytes, const void* d_send_hi, size_t send_hi_bytes, void* d_recv_hi, size_t recv_hi_bytes,
+    void* stream);
 /* `bytes` bytes of d_send to this rank itself (one RCCL group of ncclSend + ncclRecv): what a
  * one-GPU machine can check of the binding ya_comm_exchange uses. */
 int ya_comm_self_exchange(ya_comm* comm, const void* d_send, void* d_recv, size_t bytes, void* stream);

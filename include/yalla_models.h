@@ -89,46 +89,49 @@ int ya_sim_get_prop(ya_sim* sim, const char* name, int* values, int n);
 /* Links of a model that has them: n_links pairs (a, b), then copy_to_device. */
 int ya_sim_set_links(ya_sim* sim, const int* ab, int n_links, float strength);
 
-/* ---- z-slab decomposition of a Grid_solver model over ranks (SURVEY.md §8e).
- * New relative to the reference (single-GPU).  A rank owns the cells with
- * z in [z_lo, z_hi); local arrays hold own cells [0, n_own) then ghosts.  All
- * buffers are device memory (host memory on the oracle) of ya_slab_*_bytes(cap)
- * bytes: a 16-byte header {int count} and `cap` rows per field (X, old_v, global id).  One stage is
- *   pack_halo(dir 0 -> lower neighbour, 1 -> upper) ; exchange ; unpack_halo ;
- *   stage_rhs ; stage_sum -> {sum[n_floats], n_own & 4095, n_own >> 12} (n_floats + 2 floats:
- *   the count in two pieces that stay exact under a float all-reduce) ; all-reduce ; stage_update
- * and after stage 2: migrate_pack ; exchange ; migrate_unpack.  The exchange
- * itself (RCCL send/recv, all-reduce) is the caller's: yalla_amd/slab.py. */
-int ya_slab_init(ya_sim* sim, float z_lo, float z_hi, float halo_width, const int* global_ids);
-long ya_slab_halo_bytes(ya_sim* sim, int cap_cells);
-long ya_slab_migrate_bytes(ya_sim* sim, int cap_cells);
-int ya_slab_pack_halo(ya_sim* sim, int stage, int dir, void* d_buf, int cap_cells);
-/* returns the local cell count own + ghosts, or < 0 (-4 sender overflow, -5 no room) */
-int ya_slab_unpack_halo(ya_sim* sim, int stage, const void* d_buf_lo, const void* d_buf_hi, int cap_cells);
-int ya_slab_stage_rhs(ya_sim* sim, int stage);
-int ya_slab_stage_sum(ya_sim* sim, int stage, float* d_sum_and_count);
-int ya_slab_stage_update(ya_sim* sim, int stage, float dt, const float* d_total_sum_and_count);
-int ya_slab_migrate_pack(ya_sim* sim, void* d_buf_lo, void* d_buf_hi, int cap_cells);
-int ya_slab_migrate_unpack(ya_sim* sim, const void* d_buf_lo, const void* d_buf_hi, int cap_cells);
-int ya_slab_n_own(ya_sim* sim);
-
-/* The same step sequenced in C++ for the one-process-per-rank case: ya_slab_setup allocates
- * this rank's message buffers (rank r of `world` slabs has neighbours r - 1 and r + 1), a
- * transport says how they travel, ya_slab_step does one take_step of the decomposed system
- * (both Heun stages and, if `migrate`, the hand-over of cells that left the slab).
- * Transports: ya_slab_use_rccl(sim, ya_comm*) -- RCCL send/recv and all-reduce on the device
- * buffers (include/yalla_hip.h, device build only) -- or two callbacks (tests: gloo, or
- * messages staged through the host).  exchange: `kind` 0 = ghost layer, 1 = migration;
- * `bytes` from every present send buffer to that neighbour, as many into the recv buffers;
- * allreduce: in-place sum of `count` floats over all ranks.  Both return 0 on success. */
-typedef int (*ya_slab_exchange_fn)(void* ctx, int kind, const void* send_lo, void* recv_lo,
-    const void* send_hi, void* recv_hi, long bytes);
+/* ---- z-slab decomposition of a Grid_solver model over ranks (SURVEY.md section 8e).
+ * New relative to the reference (single-GPU).  A rank owns the cells with z in [z_lo, z_hi); its
+ * local arrays hold the own cells [0, n_own) and then MIRRORED cells of the two slab neighbours
+ * (their cells within halo_width of the shared face), which it advances itself with the same
+ * update kernels.  One process per rank:
+ *   ya_slab_init      this rank's share of the system (the cells in h_X[0 .. h_n) with their
+ *                     global ids); pairwise functors are called with GLOBAL ids from then on
+ *   ya_slab_setup     rank r of `world` slabs (neighbours r - 1, r + 1), message capacities in
+ *                     cells (the same on every rank: ya::slab_plan in include/slab_logic.inc)
+ *   a transport       ya_slab_use_rccl(sim, ya_comm*): RCCL send/recv and all-reduce on device
+ *                     buffers (include/yalla_hip.h, device build only), or two callbacks (tests:
+ *                     gloo, threads of one process, messages staged through the host)
+ *   ya_slab_step      one take_step of the decomposed system, this rank's part: per Heun stage
+ *                     the grid over own + mirrored cells, the forces of the tiles next to the
+ *                     faces, ONE message per neighbour -- the right-hand sides dX of the cells it
+ *                     mirrors, at their exact length, travelling beside the forces of all other
+ *                     tiles --, the all-reduce of {sum dX, cell count} (n_floats + 2 floats: the
+ *                     count in two pieces that stay exact under a float sum) and the update of
+ *                     own and mirrored cells; if `migrate`, the cells that left the slab are
+ *                     handed over afterwards and the next step chooses the mirrored cells anew.
+ *                     Between two migrations no cell may drift further than (halo_width -
+ *                     cube_size) / 2.
+ * exchange callback: `kind` 0 = mirrored cells' state and 1 = migrating cells (both fixed
+ * capacity, 16-byte header {int count} + rows), 2 = a stage's right-hand sides (bare rows);
+ * send_*_bytes from the send buffers to the lower / upper neighbour, recv_*_bytes from them into
+ * the recv buffers (a size of 0: no such message); blocking.  allreduce: in-place sum of `count`
+ * floats over all ranks.  Both return 0 on success. */
+typedef int (*ya_slab_exchange_fn)(void* ctx, int kind, const void* send_lo, long send_lo_bytes, void* recv_lo,
+    long recv_lo_bytes, const void* send_hi, long send_hi_bytes, void* recv_hi, long recv_hi_bytes);
 typedef int (*ya_slab_allreduce_fn)(void* ctx, float* buf, int count);
+int ya_slab_init(ya_sim* sim, float z_lo, float z_hi, float halo_width, const int* global_ids);
 int ya_slab_setup(ya_sim* sim, int rank, int world, int halo_cap_cells, int migrate_cap_cells);
 int ya_slab_set_transport(ya_sim* sim, ya_slab_exchange_fn exchange, ya_slab_allreduce_fn allreduce, void* ctx);
 int ya_slab_use_rccl(ya_sim* sim, void* comm);
 int ya_slab_step(ya_sim* sim, float dt, int migrate);
+int ya_slab_n_own(ya_sim* sim);
+/* own + mirrored cells as of the last step */
+int ya_slab_n_local(ya_sim* sim);
 int ya_slab_get_own(ya_sim* sim, float* X_host, int* global_ids_host);
+/* ya::slab_plan (include/slab_logic.inc) for the n cells X (n_floats floats each, z the third):
+ * cut planes bounds[world + 1], then capacities[4] = {halo_cap, mig_cap, n_max, fullest ghost
+ * layer}.  Returns 0, or -9 if an interior slab is thinner than the ghost layer. */
+int ya_slab_plan(const float* X, int n_floats, int n, int world, float cube_size, float* bounds, int* capacities);
 
 /* Device only (test hook): number of binary32 bit patterns in [first, last] for
  * which the engine's correctly rounded square root (ya::exact_sqrt, used for every

@@ -45,3 +45,6 @@ printf "%s\n" springs sorting passive_growth branching apical_constriction bendi
     epithelium gradient growth_w_wall intercalation lineage_tracing migration random_walk sorting_prot turing \
     turing_w_noise wnt write_vtk_w_mask | xargs -P 6 -I{} bash -c 'build_model {}'
 [ "$(ls "$OUT/examples" | wc -l)" -ge 19 ] || { echo "some example programs failed to build"; exit 1; }
+# What must be present on the GPU box: the tests FAIL (not skip) there when a listed binary is missing.
+( cd "$OUT" && { ls test_* | sed 's|^|oracle/_ref/|'; ls examples/* | sed 's|^|oracle/_ref/|'; } ) > "$HERE/ref_manifest.txt"
+echo "wrote oracle/ref_manifest.txt ($(wc -l < "$HERE/ref_manifest.txt") binaries)"

@@ -49,7 +49,7 @@ __device__ float3 differential_adhesion(float3 Xi, float3 r, float dist, int i, 
 }
 
 static int exchanges = 0, reductions = 0;
-int count_exchange(void*, int, const void*, void*, const void*, void*, long)
+int count_exchange(void*, int, const void*, long, void*, long, const void*, long, void*, long)
 {
     exchanges++;
     return 0;

@@ -2,7 +2,9 @@
 against this repo's headers + libyalla_hip.so by oracle/build_ref_tests.sh into
 oracle/_ref/ and run here.  test_dtypes is host-only; the others need the GPU.
 The binaries are built in the authoring container (where the reference checkout
-lives) and travel to the GPU box; they are skipped where they were never built."""
+lives) and travel to the GPU box.  oracle/ref_manifest.txt (committed, written by the build
+script) lists what was built: a listed binary that is missing FAILS its test -- only a checkout
+that never built them (no manifest entry) skips."""
 import os
 import subprocess
 
@@ -12,6 +14,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF_BIN = os.path.join(ROOT, "oracle", "_ref")
 
 
+def missing_binary(exe):
+    """Skip if the build script never produced this binary, FAIL if the committed manifest
+    says it did: git-ignored binaries that silently failed to travel must not turn 26 tests green."""
+    rel = os.path.relpath(exe, ROOT)
+    manifest = os.path.join(ROOT, "oracle", "ref_manifest.txt")
+    listed = os.path.exists(manifest) and rel in open(manifest).read().split()
+    if listed:
+        pytest.fail(f"{rel} is listed in oracle/ref_manifest.txt but missing here: the reference's own "
+                    "programs were built and did not reach this box")
+    pytest.skip(f"{exe} was not built (no reference checkout here)")
+
+
 def run(name, tmp_path, n_tests, seed=None, expect="ALL TESTS PASSED"):
     exe = os.path.join(REF_BIN, name)
     if not os.path.exists(exe):
@@ -19,7 +33,7 @@ def run(name, tmp_path, n_tests, seed=None, expect="ALL TESTS PASSED"):
             subprocess.run(["bash", os.path.join(ROOT, "oracle", "build_ref_tests.sh")], check=True,
                            capture_output=True)
         else:
-            pytest.skip(f"{exe} was not built (no reference checkout here)")
+            missing_binary(exe)
     env = dict(os.environ)
     if seed is not None:
         env["YALLA_SEED"] = str(seed)  # include/inits.cuh: pins every "any seed" initial condition

@@ -3,7 +3,7 @@ sorting.cu, passive_growth.cu and branching.cu, UNMODIFIED, compiled from where 
 reference checkout against this repo's headers + libyalla_hip.so (oracle/build_ref_tests.sh ->
 oracle/_ref/examples/) -- run to completion on the MI355X and leave the frames a ya||a user
 expects: file names, counts, sections, cell numbers, finite values.  Built in the authoring
-container, skipped where they were never built."""
+container; a binary that oracle/ref_manifest.txt lists but that is missing here FAILS its test."""
 import os
 import subprocess
 
@@ -19,7 +19,8 @@ pytestmark = pytest.mark.gpu
 def run_model(name, tmp_path, seed=1, may_end_with=None):
     exe = os.path.join(BIN, name)
     if not os.path.exists(exe):
-        pytest.skip(f"{exe} was not built (no reference checkout here)")
+        from test_reference_binaries import missing_binary
+        missing_binary(exe)
     env = dict(os.environ, YALLA_SEED=str(seed))  # pins random_sphere & co. (include/inits.cuh)
     # stdout is dropped: turing_w_noise.cu printf()s from its functor, 10^7 lines per run
     proc = subprocess.run([exe], cwd=tmp_path, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True,

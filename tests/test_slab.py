@@ -1,7 +1,7 @@
-"""z-slab decomposition (yalla_amd/slab.py): a system cut into slabs must evolve
-like the undivided system.  CPU: the orchestration on the oracle backend, in
-process (LocalComm) and across two gloo ranks (DistComm).  GPU: the device path
-with several slabs on one GPU."""
+"""z-slab decomposition (include/slab_logic.inc, yalla_amd/slab.py): a system cut into slabs must
+evolve like the undivided system.  CPU: the native step on the oracle backend, several slabs in
+one process (a host thread each) and across two gloo ranks.  GPU: the same on the device, several
+slabs sharing the one GPU."""
 import os
 import subprocess
 import sys
@@ -29,20 +29,20 @@ def reference_run(lib, n, gs, dist, seed, dt, steps, tree=False, model="springs_
 
 def slab_run(lib, X0, world, gs, dt, steps, device="cpu", migrate_every=1, model="springs_grid",
              force_variant=None):
-    bounds = slab_mod.slab_bounds(X0[:, 2], world)
-    slabs = [slab_mod.Slab(model, X0, r, world, bounds, gs, lib=lib, device=device)
-             for r in range(world)]
+    """`world` slabs of one system in this process, a host thread per slab running the native
+    step (yalla_amd.slab.run_slabs); returns the positions by global id and how many cells
+    changed owner."""
+    plan = slab_mod.slab_plan(X0, world, 1.0, lib)
+    slabs = [slab_mod.Slab(model, X0, r, world, gs, lib=lib, plan=plan) for r in range(world)]
     if force_variant is not None:
         for s in slabs:
             s.sim.set_param("force_variant", force_variant)
     if model.startswith("sorting"):
         for s in slabs:
             s.sim.set_param("n_cells", len(X0))  # types split at the GLOBAL id n / 2 (sorting.cu:24)
-    comm = slab_mod.LocalComm()
     moved = 0
     owners0 = [set(s.own_cells()[0].tolist()) for s in slabs]
-    for k in range(steps):
-        slab_mod.step(slabs, comm, dt, migrate=(k + 1) % migrate_every == 0 or k == steps - 1)
+    slab_mod.run_slabs(slabs, dt, steps, migrate_every, device_memory=device != "cpu")
     X = np.zeros_like(X0)
     seen = np.zeros(len(X0), bool)
     for r, s in enumerate(slabs):
@@ -82,9 +82,21 @@ def test_postponed_migration_oracle(oracle):
 
 def test_slabs_thinner_than_the_ghost_layer_are_refused(oracle):
     X0, _ = reference_run(oracle, 300, 50, 0.5, 3, 0.001, 0)
-    bounds = slab_mod.slab_bounds(X0[:, 2], 6)
     with pytest.raises(slab_mod.YallaError):
-        slab_mod.Slab("springs_grid", X0, 2, 6, bounds, 50, lib=oracle)
+        slab_mod.slab_plan(X0, 6, 1.0, oracle)
+
+
+def test_native_plan_is_the_quantile_plan(oracle):
+    """ya::slab_plan through the C ABI: cut planes = z-quantiles (equal cell counts), capacities
+    from the fullest ghost layer."""
+    X0, _ = reference_run(oracle, 5000, 50, 0.5, 3, 0.001, 0)
+    bounds, halo_cap, mig_cap, n_max = slab_mod.slab_plan(X0, 4, 1.0, oracle)
+    assert np.array_equal(bounds, slab_mod.slab_bounds(X0[:, 2], 4))
+    z = X0[:, 2]
+    fullest = max(max(np.count_nonzero((z >= f - 1.25) & (z < f)), np.count_nonzero((z >= f) & (z < f + 1.25)))
+                  for f in bounds[1:-1])
+    assert halo_cap == int(fullest * 1.15) + 64 and mig_cap == halo_cap // 4 + 64
+    assert n_max >= 5000 // 4 + 2 * halo_cap
 
 
 def test_id_indexed_functor_in_slabs_oracle(oracle):
@@ -108,12 +120,10 @@ def run_ranks(tmp_path, name, port, *worker_args):
     return np.load(out)
 
 
-@pytest.mark.parametrize("sequencing", ["native", "python"])
-def test_two_gloo_ranks_match_undivided_system(oracle, tmp_path, sequencing):
-    """One process per rank over gloo, world_size 2 (oracle backend): the step sequenced in
-    C++ (ya_slab_step, gloo behind the transport callbacks) and by yalla_amd/slab.py."""
-    got = run_ranks(tmp_path, "slab_gloo.npz", 29611 if sequencing == "native" else 29613,
-                    "oracle", sequencing)
+def test_two_gloo_ranks_match_undivided_system(oracle, tmp_path):
+    """One process per rank over gloo, world_size 2 (oracle backend): ya_slab_step with gloo
+    behind the transport callbacks."""
+    got = run_ranks(tmp_path, "slab_gloo.npz", 29611, "oracle")
     X0, Xref = reference_run(oracle, 3000, 50, 0.5, 3, 0.003, 6)
     assert np.array_equal(got["X0"], X0)
     scale = np.abs(Xref).max()
@@ -122,7 +132,7 @@ def test_two_gloo_ranks_match_undivided_system(oracle, tmp_path, sequencing):
 
 def test_two_gloo_ranks_id_indexed_functor(oracle, tmp_path):
     """sorting_grid (functor indexed by global id) through the C++-sequenced step, 2 ranks."""
-    got = run_ranks(tmp_path, "slab_gloo_sorting.npz", 29615, "oracle", "native", "sorting_grid")
+    got = run_ranks(tmp_path, "slab_gloo_sorting.npz", 29615, "oracle", "sorting_grid")
     X0, Xref = reference_run(oracle, 3000, 50, 0.5, 3, 0.002, 6, model="sorting_grid")
     assert np.array_equal(got["X0"], X0)
     scale = np.abs(Xref).max()
@@ -130,13 +140,11 @@ def test_two_gloo_ranks_id_indexed_functor(oracle, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("sequencing", ["native", "python"])
-def test_two_ranks_sharing_one_gpu_match_undivided_system(device, tmp_path, sequencing):
+def test_two_ranks_sharing_one_gpu_match_undivided_system(device, tmp_path):
     """The one-process-per-rank path on the device, world_size 2.  RCCL refuses two ranks on
     one GPU, so the transport is gloo with the messages staged through host memory; the
-    sequencing (C++ ya_slab_step or slab.py) and all device work are what bench.py runs."""
-    got = run_ranks(tmp_path, "slab_gloo_device.npz", 29612 if sequencing == "native" else 29614,
-                    "device", sequencing)
+    sequencing (ya_slab_step) and all device work are what bench.py runs."""
+    got = run_ranks(tmp_path, "slab_gloo_device.npz", 29612, "device")
     X0, Xref = reference_run(device, 40000, 50, 0.5, 3, 0.003, 6)
     assert np.array_equal(got["X0"], X0)
     scale = np.abs(Xref).max()
@@ -209,12 +217,10 @@ def test_rccl_communicator_single_rank(device):
         assert (comm.rank, comm.world) == (0, 1)
         assert comm.allreduce_host([1.5, 2.0]) == [1.5, 2.0]
         X0, Xref = reference_run(device, 20000, 50, 0.5, 3, 0.003, 4)
-        bounds = slab_mod.slab_bounds(X0[:, 2], 1)
-        sl = slab_mod.Slab("springs_grid", X0, 0, 1, bounds, 50, lib=device, device="hip",
-                           python_buffers=False)
-        sl.setup_native_step(comm=comm)
+        sl = slab_mod.Slab("springs_grid", X0, 0, 1, 50, lib=device)
+        sl.use(comm=comm)
         for _ in range(4):
-            sl.step_native(0.003)
+            sl.step(0.003)
         gid, X = sl.own_cells()
         full = np.zeros_like(X0)
         full[gid] = X

@@ -1,7 +1,9 @@
 // Rehearsal of north_star's multi-GPU configuration on ONE GPU: a 10 M-cell springs system cut
 // into W z-slabs, every slab a Solution<float3, Slab_grid_solver> stepped by its own host thread
 // through the NATIVE sequencing (Slab_grid_solver::take_step = slab_step) with a callback
-// transport, exactly as W ranks would -- except that the slabs share one GPU.  So that each
+// transport, exactly as W ranks would -- except that the slabs share one GPU (and that a
+// callback transport is synchronous: with RCCL the stage's message travels on its own stream
+// beside the interior tiles' forces; here the slab simply finishes its launches first).  So that each
 // slab's device time is what it would be with a GPU of its own, the threads take turns: a
 // thread holds the GPU from the moment a transport call returns until it enters the next one
 // (where it drains the device and stops its clock), and the transport itself -- the copies
@@ -38,9 +40,30 @@ __device__ float3 spring(float3 Xi, float3 r, float dist, int i, int j)  // exam
     return r * (0.5f - dist) / dist;
 }
 
+// One empty kernel per rank: launched whenever a slab takes the GPU, so that a kernel trace of
+// this program (rocprofv3 --kernel-trace) can be cut into the slabs' segments
+// (tools/slab_trace_summary.py: device-busy time per slab and step).
+template<int RANK>
+__global__ void slab_takes_the_gpu() {}
+static void mark(int rank)
+{
+    switch (rank & 7) {
+        case 0: slab_takes_the_gpu<0><<<1, 1>>>(); break;
+        case 1: slab_takes_the_gpu<1><<<1, 1>>>(); break;
+        case 2: slab_takes_the_gpu<2><<<1, 1>>>(); break;
+        case 3: slab_takes_the_gpu<3><<<1, 1>>>(); break;
+        case 4: slab_takes_the_gpu<4><<<1, 1>>>(); break;
+        case 5: slab_takes_the_gpu<5><<<1, 1>>>(); break;
+        case 6: slab_takes_the_gpu<6><<<1, 1>>>(); break;
+        default: slab_takes_the_gpu<7><<<1, 1>>>(); break;
+    }
+}
+
 using Clock = std::chrono::steady_clock;
 using Slab = Solution<float3, Slab_grid_solver>;
-constexpr int SEGMENTS = 8;  // per step: pack | rhs 1 | update 1 + pack | rhs 2 | update 2 (+ migrate pack) | unpack
+// segments of a step (a new one begins whenever a transport call returns): [re-halo: pack |
+// unpack +] build + forces 1 | sum 1 | update 1 + build + forces 2 | sum 2 | update 2 (+ migrate pack) | migrate unpack
+constexpr int SEGMENTS = 10;
 
 struct Barrier {
     std::mutex m;
@@ -67,6 +90,7 @@ struct Shared {
     std::vector<const void*> send_lo, send_hi;
     std::vector<float*> sums;
     bool timing = false;
+    bool markers = false;  // YALLA_REHEARSAL_MARKERS=1: a marker kernel per segment (for traces; costs a launch)
     explicit Shared(int w) : world(w), barrier(w), send_lo(w), send_hi(w), sums(w) {}
 };
 
@@ -76,6 +100,7 @@ struct Rank {
     Clock::time_point started;
     int segment = 0;
     double seconds[SEGMENTS] = {0};
+    long message_bytes = 0;  // right-hand-side messages sent during the timed steps
     void stop()  // the device is drained, the clock stopped, the GPU handed on
     {
         (void)hipDeviceSynchronize();
@@ -87,23 +112,26 @@ struct Rank {
     void start()
     {
         shared->gpu.lock();
+        if (shared->markers) mark(rank);
         started = Clock::now();
     }
 };
 
-static int exchange_cb(void* ctx, int kind, const void* send_lo, void* recv_lo, const void* send_hi, void* recv_hi,
-    long bytes)
+static int exchange_cb(void* ctx, int kind, const void* send_lo, long send_lo_bytes, void* recv_lo, long recv_lo_bytes,
+    const void* send_hi, long send_hi_bytes, void* recv_hi, long recv_hi_bytes)
 {
     Rank& me = *(Rank*)ctx;
     Shared& sh = *me.shared;
     me.stop();
     sh.send_lo[me.rank] = send_lo;
     sh.send_hi[me.rank] = send_hi;
+    if (sh.timing && kind == 2) me.message_bytes += send_lo_bytes + send_hi_bytes;
     sh.barrier.wait();
     // what RCCL send/recv would move over xGMI: device-to-device copies, outside the clocks
-    if (recv_lo && me.rank > 0) (void)hipMemcpy(recv_lo, sh.send_hi[me.rank - 1], (size_t)bytes, hipMemcpyDeviceToDevice);
-    if (recv_hi && me.rank + 1 < sh.world)
-        (void)hipMemcpy(recv_hi, sh.send_lo[me.rank + 1], (size_t)bytes, hipMemcpyDeviceToDevice);
+    if (recv_lo_bytes > 0 && me.rank > 0)
+        (void)hipMemcpy(recv_lo, sh.send_hi[me.rank - 1], (size_t)recv_lo_bytes, hipMemcpyDeviceToDevice);
+    if (recv_hi_bytes > 0 && me.rank + 1 < sh.world)
+        (void)hipMemcpy(recv_hi, sh.send_lo[me.rank + 1], (size_t)recv_hi_bytes, hipMemcpyDeviceToDevice);
     (void)hipDeviceSynchronize();
     sh.barrier.wait();
     me.start();
@@ -133,6 +161,9 @@ static int allreduce_cb(void* ctx, float* buf, int count)
 
 int main(int argc, char** argv)
 {
+    // every slab has a stream for its interior launch (and the step's own): enough hardware
+    // queues that they do not share one with another slab's stream, as W processes would not
+    setenv("GPU_MAX_HW_QUEUES", "16", 0);
     const int n = argc > 1 ? atoi(argv[1]) : 10000000;
     const int world = argc > 2 ? atoi(argv[2]) : 8;
     const int steps = argc > 3 ? atoi(argv[3]) : 16;
@@ -165,6 +196,7 @@ int main(int argc, char** argv)
         return 1;
     }
     Shared shared{world};
+    shared.markers = getenv("YALLA_REHEARSAL_MARKERS") != nullptr;
     std::vector<std::unique_ptr<Slab>> slabs;
     std::vector<Rank> ranks(world);
     for (int r = 0; r < world; r++) {
@@ -255,14 +287,15 @@ int main(int argc, char** argv)
         for (int g = 0; g < SEGMENTS; g++) sum += ranks[r].seconds[g];
         slowest_slab = std::max(slowest_slab, sum);
         total_own += owns[r];
-        printf("%s{\"rank\": %d, \"n_own\": %d, \"n_ghost\": %d, \"ms_per_step\": %.4f, \"segments_ms\": [", r ? ", " : "",
-            r, owns[r], ghosts[r], sum / steps * 1e3);
+        printf("%s{\"rank\": %d, \"n_own\": %d, \"n_ghost\": %d, \"ms_per_step\": %.4f, \"rhs_message_bytes_per_stage\": %.0f, "
+               "\"segments_ms\": [", r ? ", " : "", r, owns[r], ghosts[r], sum / steps * 1e3,
+            (double)ranks[r].message_bytes / (2.0 * steps));
         for (int g = 0; g < SEGMENTS; g++) printf("%s%.4f", g ? ", " : "", ranks[r].seconds[g] / steps * 1e3);
         printf("]}");
     }
-    printf("], \"segment_names\": [\"pack 1\", \"unpack + build + force + sum 1\", \"update 1 + pack 2\", "
-           "\"unpack + build + force + sum 2\", \"update 2 (+ migrate pack)\", \"migrate unpack\", \"-\", \"-\"], "
-           "\"segment_max_ms\": [");
+    printf("], \"segment_note\": \"a segment ends at every transport call: per stage 'build + both force launches + "
+           "packing the neighbours\' rows', 'join + reduction', then 'update' joins the next stage\'s first segment; steps that "
+           "begin with a re-halo or end with a migration have two more each\", \"segment_max_ms\": [");
     for (int g = 0; g < SEGMENTS; g++) printf("%s%.4f", g ? ", " : "", seg_max[g] / steps * 1e3);
     printf("], \"parity\": {\"take_steps\": %d, \"cells_missing\": %ld, \"cells_beyond_1e-5\": %ld, \"max_abs_diff\": %.3g, "
            "\"scale\": %.4g}", warmup + steps, missing, beyond, max_diff, scale);

@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Device-busy time per slab and step from a kernel trace of tools/slab_rehearsal run with
+YALLA_REHEARSAL_MARKERS=1 (a marker kernel `slab_takes_the_gpu<r>` whenever slab r takes the GPU):
+
+    python tools/slab_trace_summary.py <k_kernel_trace.csv> <steps incl. warm-up> [skip_steps]
+
+Per slab: the union of its kernels' intervals (overlapping launches counted once), split into the
+force kernel and everything else, per step; and the same for the undivided system that the
+program steps first.  This is the compute side of a rank's step WITHOUT host launch gaps and
+without the rehearsal's device synchronisations -- the lower bracket of the projection, next to
+the program's own wall-clock figures (the upper one)."""
+import collections
+import csv
+import json
+import re
+import sys
+
+
+def union(intervals):
+    total, end = 0, -1
+    for a, b in sorted(intervals):
+        if a > end:
+            total += b - a
+            end = b
+        elif b > end:
+            total += b - end
+            end = b
+    return total
+
+
+def main(path, steps, skip=0):
+    rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(path))]
+    rows.sort()
+    first_marker = next(i for i, r in enumerate(rows) if "slab_takes_the_gpu" in r[2])
+    whole = rows[:first_marker]
+    last_raw = max(i for i, r in enumerate(whole) if "heun_step_raw" in r[2])
+    whole = whole[: last_raw + 1]
+    n_whole_steps = sum("heun_step_raw" in r[2] for r in whole)
+    per_rank = collections.defaultdict(list)
+    rank = None
+    for a, b, name in rows[first_marker:]:
+        m = re.search(r"slab_takes_the_gpu<(\d+)>", name) or re.search(r"slab_takes_the_gpuILi(\d+)E", name)
+        if m:
+            rank = int(m.group(1))
+            continue
+        per_rank[rank].append((a, b, name))
+    out = {"undivided_device_ms_per_step": union([(a, b) for a, b, _ in whole]) / n_whole_steps / 1e6,
+           "undivided_steps": n_whole_steps, "slabs": []}
+    worst = 0
+    for r in sorted(per_rank):
+        ks = per_rank[r]
+        busy = union([(a, b) for a, b, _ in ks]) / steps / 1e6
+        force = union([(a, b) for a, b, n in ks if "grid_force" in n]) / steps / 1e6
+        copies = sum(b - a for a, b, n in ks if "copyBuffer" in n or "fillBuffer" in n) / steps / 1e6
+        out["slabs"].append({"rank": r, "device_ms_per_step": busy, "force_ms_per_step": force,
+                             "copy_fill_ms_per_step": copies, "launches_per_step": len(ks) / steps})
+        worst = max(worst, busy)
+    out["slowest_slab_device_ms_per_step"] = worst
+    out["projected_speedup_device_time_only"] = out["undivided_device_ms_per_step"] / worst
+    out["note"] = ("device-busy time only (no host launch gaps, no RCCL latency, no xGMI transfer time; the rehearsal's "
+                   "own copies between slabs are attributed to no slab): the optimistic bracket of the projection")
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]) if len(sys.argv) > 3 else 0)

@@ -49,21 +49,14 @@ MODELS_ABI = {
     "ya_sim_set_links": (C.c_int, [_sim, _pi, C.c_int, C.c_float]),
     "ya_sim_set_reduce_order": (C.c_int, [_sim, C.c_int]),
     "ya_slab_init": (C.c_int, [_sim, C.c_float, C.c_float, C.c_float, _pi]),
-    "ya_slab_halo_bytes": (C.c_long, [_sim, C.c_int]),
-    "ya_slab_migrate_bytes": (C.c_long, [_sim, C.c_int]),
-    "ya_slab_pack_halo": (C.c_int, [_sim, C.c_int, C.c_int, C.c_void_p, C.c_int]),
-    "ya_slab_unpack_halo": (C.c_int, [_sim, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
-    "ya_slab_stage_rhs": (C.c_int, [_sim, C.c_int]),
-    "ya_slab_stage_sum": (C.c_int, [_sim, C.c_int, C.c_void_p]),
-    "ya_slab_stage_update": (C.c_int, [_sim, C.c_int, C.c_float, C.c_void_p]),
-    "ya_slab_migrate_pack": (C.c_int, [_sim, C.c_void_p, C.c_void_p, C.c_int]),
-    "ya_slab_migrate_unpack": (C.c_int, [_sim, C.c_void_p, C.c_void_p, C.c_int]),
     "ya_slab_n_own": (C.c_int, [_sim]),
+    "ya_slab_n_local": (C.c_int, [_sim]),
     "ya_slab_setup": (C.c_int, [_sim, C.c_int, C.c_int, C.c_int, C.c_int]),
     "ya_slab_set_transport": (C.c_int, [_sim, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ya_slab_use_rccl": (C.c_int, [_sim, C.c_void_p]),
     "ya_slab_step": (C.c_int, [_sim, C.c_float, C.c_int]),
     "ya_slab_get_own": (C.c_int, [_sim, _pf, _pi]),
+    "ya_slab_plan": (C.c_int, [_pf, C.c_int, C.c_int, C.c_int, C.c_float, _pf, _pi]),
     "ya_check_sqrt": (C.c_long, [C.c_uint, C.c_uint]),
     "ya_check_reciprocal": (C.c_long, [C.c_uint, C.c_uint]),
     "ya_sim_profile": (C.c_int, [_sim, C.c_int]),
@@ -80,7 +73,7 @@ CORE_ABI = [
     "ya_n_read_begin", "ya_n_read_end", "ya_grid_status", "ya_reduce_mean",
     "ya_reduce_workspace_bytes", "ya_select_z", "ya_select_workspace_bytes", "ya_gather_rows",
     "ya_append_rows", "ya_comm_unique_id", "ya_comm_create", "ya_comm_create_from_env",
-    "ya_comm_destroy", "ya_comm_rank", "ya_comm_world", "ya_comm_exchange",
+    "ya_comm_destroy", "ya_comm_rank", "ya_comm_world", "ya_comm_exchange", "ya_comm_exchange_v",
     "ya_comm_allreduce_sum", "ya_comm_allreduce_host", "ya_comm_self_exchange",
 ]
 

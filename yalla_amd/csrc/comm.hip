@@ -316,6 +316,32 @@ int ya_comm_exchange(ya_comm* c, const void* d_send_lo, void* d_recv_lo, const v
     return 0;
 }
 
+int ya_comm_exchange_v(ya_comm* c, const void* d_send_lo, size_t send_lo_bytes, void* d_recv_lo,
+    size_t recv_lo_bytes, const void* d_send_hi, size_t send_hi_bytes, void* d_recv_hi, size_t recv_hi_bytes,
+    void* stream)
+{
+    if (!c) return (int)hipErrorInvalidValue;
+    if (c->world == 1) return 0;
+    Rccl* r = rccl();
+    if (!r) return 999;
+    hipStream_t st = (hipStream_t)stream;
+    const bool lo = c->rank > 0, hi = c->rank + 1 < c->world;
+    if ((lo && ((send_lo_bytes && !d_send_lo) || (recv_lo_bytes && !d_recv_lo))) ||
+        (hi && ((send_hi_bytes && !d_send_hi) || (recv_hi_bytes && !d_recv_hi))))
+        return (int)hipErrorInvalidValue;
+    YA_RCCL(r->GroupStart(), "ncclGroupStart");
+    if (lo && send_lo_bytes)
+        YA_RCCL_IN_GROUP(r->Send(d_send_lo, send_lo_bytes, NCCL_INT8, c->rank - 1, c->comm, st), "ncclSend (lower slab)");
+    if (lo && recv_lo_bytes)
+        YA_RCCL_IN_GROUP(r->Recv(d_recv_lo, recv_lo_bytes, NCCL_INT8, c->rank - 1, c->comm, st), "ncclRecv (lower slab)");
+    if (hi && send_hi_bytes)
+        YA_RCCL_IN_GROUP(r->Send(d_send_hi, send_hi_bytes, NCCL_INT8, c->rank + 1, c->comm, st), "ncclSend (upper slab)");
+    if (hi && recv_hi_bytes)
+        YA_RCCL_IN_GROUP(r->Recv(d_recv_hi, recv_hi_bytes, NCCL_INT8, c->rank + 1, c->comm, st), "ncclRecv (upper slab)");
+    YA_RCCL(r->GroupEnd(), "ncclGroupEnd");
+    return 0;
+}
+
 int ya_comm_self_exchange(ya_comm* c, const void* d_send, void* d_recv, size_t bytes, void* stream)
 {
     if (!c || !c->comm || !d_send || !d_recv) return (int)hipErrorInvalidValue;
