@@ -221,12 +221,33 @@ __global__ void check_sqrt_all(unsigned first, unsigned last, unsigned long long
 // 10^6 cells, so the stencil rows a tile reads (the tiles before and after it, one
 // grid row and one grid plane away) are L2 hits.  Bijective for any grid size; a
 // wrong placement guess would cost speed, not correctness.
-__device__ __forceinline__ int xcd_contiguous_tile(const int block, const int n_blocks)
+__device__ __forceinline__ int xcd_eighth_tile(const int block, const int n_blocks)
 {
     constexpr int XCDS = 8;
     const int xcd = block % XCDS, turn = block / XCDS;
     const int q = n_blocks / XCDS, r = n_blocks % XCDS;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + turn;
+}
+// Each XCD gets TWO contiguous sixteenths: one from the lower half of the tiles and the
+// corresponding one from the upper half.  Tiles are in cube order (z-major), and a tile's cost
+// follows the local density of neighbours: for a ball of cells it rises from the first tiles
+// (a polar cap: many surface cells) to the middle and falls again, so eighths in order leave
+// the XCDs of the caps idle at the end of a launch while those of the equator still work.
+// Pairing sixteenth k of the lower half with sixteenth k of the upper half evens that out and
+// keeps an XCD's L2 to two contiguous ranges.
+#ifndef YA_XCD_RANGES
+#define YA_XCD_RANGES 2  /* contiguous ranges of tiles per XCD (1 = plain eighths) */
+#endif
+__device__ __forceinline__ int xcd_contiguous_tile(const int block, const int n_blocks)
+{
+    constexpr int RANGES = YA_XCD_RANGES;
+    // parts of a multiple of 8 tiles each (block and block - k * part then sit on the same XCD);
+    // the last part takes the remainder
+    const int part = (n_blocks / RANGES) & ~7;
+    if (RANGES == 1 || part == 0) return xcd_eighth_tile(block, n_blocks);
+    const int p = min(block / part, RANGES - 1);
+    const int first = p * part;
+    return first + xcd_eighth_tile(block - first, p == RANGES - 1 ? n_blocks - first : part);
 }
 
 // Test hook: the same for ya::reciprocal (dtypes.cuh) against 1.0f / x.

@@ -1,10 +1,11 @@
 #!/bin/bash
 # Everything one entry of the profiles/ directory is made from, in one gpurun call:
-#   gpu_profile_round.sh <tag> [bench.py arguments ...]
+#   gpu_profile_round.sh <tag> <counters key> <commit> [bench.py arguments ...]
 # the bench line (with cpu_baseline), rocprofv3 kernel stats of the same command, and the PMC
 # passes (traffic: FETCH_SIZE and WRITE_SIZE in separate passes; SQ / cache counters).
-# Afterwards, here: python tools/roofline_json.py gpurun_out/<tag> profiles/r03_counters.json <key> "<args>"
-tag=${1:-round}; shift
+# The counters' summary (tools/roofline_json.py -> $out/counters.json, one entry) is made on the box and
+# the raw per-dispatch CSVs are dropped there: gpurun carries at most 64 MiB back.
+tag=${1:-round}; key=${2:-none}; head=${3:-unknown}; shift 3
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag; mkdir -p $out
 cd $GRAFT_REPO_ROOT
 state=""
@@ -26,7 +27,7 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" \
   i=$((i+1))
   rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $out/pmc$i -o p -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 10 --warmup 2 "$@" $state > $out/pmc$i.json 2> $out/pmc$i.err
 done
-python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py "$out/pmc*/*counter_collection.csv" > $out/pmc_summary.txt
-# keep what is judged small: the per-kernel stats and the counter files of the force kernel only
-for d in $out/pmc*; do rm -f $d/*agent_info.csv; done
+python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py "$out/pmc*/*counter_collection.csv" grid_force > $out/pmc_summary.txt
+python3 $GRAFT_REPO_ROOT/tools/roofline_json.py $out $out/counters.json $key "$*" $head > $out/counters.log 2>&1
+rm -rf $out/pmc? $out/stats/*agent_info.csv $out/stats/*kernel_trace.csv
 ls $out

@@ -2,7 +2,10 @@
 """One entry of profiles/r03_counters.json from the rocprofv3 PMC passes of a bench.py command
 (tools/gpu_profile_round.sh): per-launch means for the dominant kernel (grid_force_bits).
 
-    python tools/roofline_json.py gpurun_out/<tag> profiles/r03_counters.json <key> "<bench args>"
+    python tools/roofline_json.py gpurun_out/<tag> <out.json> <key> "<bench args>" [commit]
+
+(tools/gpu_profile_round.sh runs it on the GPU box; tools/merge_counters.py folds the entries into
+profiles/r03_counters.json)
 
 Definitions (every input is a raw counter kept in profiles/r03_pmc_<key>.txt):
   kernel_cycles       GRBM_GUI_ACTIVE / 8                 (the counter sums the 8 XCDs)
@@ -32,7 +35,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL = "grid_force_bits"
+KERNEL = "grid_force"  # grid_force_bits, or grid_force_coop where the model declared its functor stateless
 PROBE_VOP2_MIX_NS = 1.012   # profiles/r03_valu_probe.jsonl: distance_test_mix, 8 waves per SIMD
 PROBE_VOP2_MIX_CYCLES, PROBE_VOP2_MIX_GHZ = 2.23, 2.207
 PROBE_FMA_NS, PROBE_FMA_CYCLES, PROBE_FMA_GHZ = 1.613, 3.29, 2.037
@@ -47,7 +50,7 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
-def main(src, dst, key, bench_args):
+def main(src, dst, key, bench_args, head=None):
     agg = collections.defaultdict(list)
     names = collections.Counter()
     durations = []
@@ -94,8 +97,8 @@ def main(src, dst, key, bench_args):
         "lds_busy_frac": m["SQ_LDS_IDX_ACTIVE"] / (256 * cycles),
         "wait_frac": m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"],
         "kernel_sha": kernel_source_sha(),
-        "head": subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True,
-                               text=True).stdout.strip() or None,
+        "head": head or subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True,
+                                       text=True).stdout.strip() or None,
         "command": "rocprofv3 --kernel-trace --pmc <pass> -- python3 bench.py --no-cpu-baseline --steps 10 --warmup 2 "
                    + bench_args + " (tools/gpu_profile_round.sh; FETCH_SIZE and WRITE_SIZE in passes of their own)",
     }
@@ -109,4 +112,5 @@ def main(src, dst, key, bench_args):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else "")
+    main(sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else "",
+         sys.argv[5] if len(sys.argv) > 5 else None)
