@@ -7,11 +7,9 @@
 //                                                              // selects GPU LOCAL_RANK, then ncclCommInitRank -- call it
 //                                                              // BEFORE constructing the Solution (its arrays live on the
 //                                                              // device that is current then)
-//     Solution<float3, Slab_grid_solver> cells{n_max, grid_size, cube_size};
-//     ... fill cells.h_X[0 .. n_own) with THIS rank's cells (z in [z_lo, z_hi)), *cells.h_n = n_own ...
-//     cells.copy_to_device();
-//     cells.slab_init(z_lo, z_hi, 1.25f * cube_size, global_ids, n_own);   // global_ids: host array, one per own cell
-//     cells.slab_setup(ya_comm_rank(comm), ya_comm_world(comm), halo_cap, migrate_cap);   // the same on every rank
+//     const ya::Slab_plan plan = ya::slab_plan(whole, n, ya_comm_world(comm), cube_size);   // whole[0 .. n): the system, on every rank
+//     Solution<float3, Slab_grid_solver> cells{plan.n_max, grid_size, cube_size};
+//     cells.slab_adopt(plan, ya_comm_rank(comm), whole, n, cells.h_X, cells.h_n);    // this rank's cells, slab_init, slab_setup
 //     cells.slab_use_rccl(comm);
 //     for (...) cells.take_step<my_force>(dt);                  // exchanges, all-reduces and migration inside
 //     n_own = cells.slab.n_own;  cells.copy_to_host();          // own cells are h_X[0 .. n_own), their ids: get_own(X, ids)

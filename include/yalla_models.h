@@ -132,6 +132,12 @@ int ya_slab_get_own(ya_sim* sim, float* X_host, int* global_ids_host);
  * cut planes bounds[world + 1], then capacities[4] = {halo_cap, mig_cap, n_max, fullest ghost
  * layer}.  Returns 0, or -9 if an interior slab is thinner than the ghost layer. */
 int ya_slab_plan(const float* X, int n_floats, int n, int world, float cube_size, float* bounds, int* capacities);
+/* Plan + this rank's share in one call (ya::slab_plan, Slab_grid_solver::slab_adopt): the sim (made
+ * with n_max >= the plan's) takes the cells of X (n points of the sim's n_floats floats, the whole
+ * system, the same on every rank) whose z lies in rank's slab, in ascending global id, and is
+ * initialised and set up for stepping (ya_slab_init + ya_slab_setup).  Returns 0, -9 (a slab
+ * thinner than the ghost layer) or -5 (n_max too small). */
+int ya_slab_decompose(ya_sim* sim, const float* X, int n, int rank, int world, float cube_size);
 
 /* Device only (test hook): number of binary32 bit patterns in [first, last] for
  * which the engine's correctly rounded square root (ya::exact_sqrt, used for every

@@ -42,6 +42,11 @@ def draw(seed):
     stage_v = bool(rng.random() < 0.5)
     if lanes and model.endswith("_grid"):
         variant = 3
+    # round 3 (drawn after everything else again): a third of the grid cases leave the choice to the
+    # engine (force_variant -1: the models' functors are declared stateless, so small systems go to
+    # grid_force_coop with the lanes chosen from n); Tile_solver cases always do (lanes_per_cell 0)
+    if model.endswith("_grid") and rng.random() < 0.33:
+        variant, lanes = -1, 0
     return dict(model=model, n=n, gs=max(gs, 8), cs=cs, dist=dist, seed=int(seed), dt=dt, steps=steps,
                 variant=variant, lanes=lanes if variant == 3 else 0, stage_v=stage_v)
 

@@ -206,13 +206,7 @@ int main(int argc, char** argv)
     for (int r = 0; r < world; r++) {
         slabs.emplace_back(new Slab{plan.n_max, gs, 1.f});
         Slab& s = *slabs.back();
-        std::vector<int> gid((size_t)plan.n_own[r]);
-        const int own = ya::slab_own_cells(plan, r, X0.data(), n, s.h_X, gid.data());
-        *s.h_n = own;
-        s.copy_to_device();
-        if (s.slab_init(plan.bounds[r], plan.bounds[r + 1], plan.halo, gid.data(), own) != 0 ||
-            s.slab_setup(r, world, plan.halo_cap, plan.mig_cap) != 0)
-            return 2;
+        if (s.slab_adopt(plan, r, X0.data(), n, s.h_X, s.h_n) != 0) return 2;
         s.d_global_id = nullptr;  // spring only compares i with j (as bench.py runs it)
         ranks[r].shared = &shared;
         ranks[r].rank = r;

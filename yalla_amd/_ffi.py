@@ -57,6 +57,7 @@ MODELS_ABI = {
     "ya_slab_step": (C.c_int, [_sim, C.c_float, C.c_int]),
     "ya_slab_get_own": (C.c_int, [_sim, _pf, _pi]),
     "ya_slab_plan": (C.c_int, [_pf, C.c_int, C.c_int, C.c_int, C.c_float, _pf, _pi]),
+    "ya_slab_decompose": (C.c_int, [_sim, _pf, C.c_int, C.c_int, C.c_int, C.c_float]),
     "ya_check_sqrt": (C.c_long, [C.c_uint, C.c_uint]),
     "ya_check_reciprocal": (C.c_long, [C.c_uint, C.c_uint]),
     "ya_sim_profile": (C.c_int, [_sim, C.c_int]),

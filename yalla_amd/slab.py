@@ -259,24 +259,23 @@ class Slab:
     model, decomposed (ya_slab_init / ya_slab_setup) and given a transport."""
 
     def __init__(self, model, X_all, rank, world, grid_size, cube_size=1.0, lib=None, global_ids=True, plan=None):
-        X_all = np.asarray(X_all, dtype=np.float32)
+        X_all = np.ascontiguousarray(X_all, dtype=np.float32)
         self.rank, self.world = rank, world
         bounds, self.halo_cap, self.mig_cap, n_max = plan if plan is not None else slab_plan(X_all, world, cube_size, lib)
         self.z_lo, self.z_hi = float(bounds[rank]), float(bounds[rank + 1])
-        z = X_all[:, 2]
-        own = np.nonzero((z >= self.z_lo) & (z < self.z_hi))[0].astype(np.int32)
         self.sim = Solution(model, n_max, grid_size, cube_size, lib=lib)
         self.n_floats = self.sim.n_floats
-        self.sim.h_X[: len(own)] = X_all[own]
-        self.sim.h_n = len(own)
-        self.sim.copy_to_device()
+        assert X_all.shape[1] == self.n_floats, "the whole system's points must have the model's point type"
         lib = self.sim.lib
         self._lib, self._h = lib, self.sim._h
-        _check(lib.ya_slab_init(self._h, self.z_lo, self.z_hi, 1.25 * cube_size,
-                                own.ctypes.data_as(C.POINTER(C.c_int))), "ya_slab_init")
+        # this rank's cells, their global ids, ya_slab_init and ya_slab_setup: all native
+        code = lib.ya_slab_decompose(self._h, X_all.ctypes.data_as(C.POINTER(C.c_float)), len(X_all), rank, world,
+                                     float(cube_size))
+        if code == -9:
+            raise YallaError("a slab is thinner than the ghost layer: use fewer slabs for this system")
+        _check(code, "ya_slab_decompose")
         if not global_ids:  # functors that only compare i with j: spare the id gather per pair
             self.sim.set_param("slab_global_ids", 0)
-        _check(lib.ya_slab_setup(self._h, rank, world, self.halo_cap, self.mig_cap), "ya_slab_setup")
         self._transport = None
 
     def use(self, comm=None, transport=None):
