@@ -1,6 +1,8 @@
 """One rank of the gloo slab tests (launched by torch.distributed.run):
-    slab_worker.py <out.npz> [oracle|device] [model]
-The step is sequenced in C++ (ya_slab_step) with gloo behind the transport callbacks."""
+    slab_worker.py <out.npz> [oracle|device|rccl] [model]
+The step is sequenced in C++ (ya_slab_step); `oracle` / `device`: gloo behind the transport callbacks
+(device: both ranks on GPU 0, messages staged through the host); `rccl`: one GPU per rank, the
+messages through libyalla_hip.so's own RCCL communicator (needs as many GPUs as ranks)."""
 import os
 import sys
 
@@ -16,7 +18,14 @@ from yalla_amd.solution import Solution
 def main(out, backend="oracle", model="springs_grid"):
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    if backend == "device":  # both ranks on GPU 0, device buffers staged through the host
+    comm = None
+    if backend == "rccl":    # one GPU per rank: the communicator selects GPU LOCAL_RANK itself
+        os.environ["MASTER_PORT"] = str(int(os.environ["MASTER_PORT"]) + 7)  # its own rendezvous port
+        comm = slab_mod.NativeComm(port_offset=1)
+        assert (comm.rank, comm.world) == (rank, world)
+        lib = _ffi.device_lib()
+        n, gs = 40000, 50
+    elif backend == "device":  # both ranks on GPU 0, device buffers staged through the host
         import torch
         torch.cuda.set_device(0)
         lib = _ffi.device_lib()
@@ -31,7 +40,10 @@ def main(out, backend="oracle", model="springs_grid"):
     sl = slab_mod.Slab(model, X0, rank, world, gs, lib=lib)
     if model.startswith("sorting"):
         sl.sim.set_param("n_cells", n)  # the functor splits the types at the GLOBAL id n / 2
-    sl.use(transport=slab_mod.CallbackTransport(device_memory=backend == "device"))
+    if comm is not None:
+        sl.use(comm=comm)
+    else:
+        sl.use(transport=slab_mod.CallbackTransport(device_memory=backend == "device"))
     for _ in range(6):
         sl.step(dt)
     gid, X = sl.own_cells()

@@ -152,6 +152,21 @@ def test_two_ranks_sharing_one_gpu_match_undivided_system(device, tmp_path):
 
 
 @pytest.mark.gpu
+def test_two_ranks_over_rccl_match_undivided_system(device, tmp_path):
+    """One GPU per rank, the messages through libyalla_hip.so's own RCCL communicator (ncclSend /
+    ncclRecv on the communication stream beside the interior launch, ncclAllReduce): the path
+    `bench.py --gpus N` takes.  Needs two GPUs: skipped on the one-GPU boxes of this build."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU here: RCCL refuses two ranks on it")
+    got = run_ranks(tmp_path, "slab_rccl.npz", 29618, "rccl")
+    X0, Xref = reference_run(device, 40000, 50, 0.5, 3, 0.003, 6)
+    assert np.array_equal(got["X0"], X0)
+    scale = np.abs(Xref).max()
+    assert np.abs(got["X"] - Xref).max() <= 1e-5 * scale
+
+
+@pytest.mark.gpu
 def test_id_indexed_functor_in_slabs_device(device):
     """sorting_grid in 2 and 4 slabs on the device against the undivided system."""
     for world in (2, 4):
