@@ -384,7 +384,14 @@ def main(argv=None):
         from yalla_amd import slab as slab_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        native_comm = slab_mod.NativeComm(port_offset=1)   # RCCL communicator of libyalla_hip.so
+        # RCCL communicator of libyalla_hip.so; its unique id travels through the rendezvous
+        # store the launcher already serves on MASTER_PORT (the engine's own TCP hand-over on
+        # MASTER_PORT + 1 if that store cannot be reached)
+        try:
+            native_comm = slab_mod.NativeComm.over_store(rank, world)
+        except (RuntimeError, ValueError, OSError) as err:
+            print(f"bench.py: rank {rank}: no rendezvous store ({err}); id over TCP", file=sys.stderr)
+            native_comm = slab_mod.NativeComm(port_offset=1)
         assert (native_comm.rank, native_comm.world) == (rank, world)
 
     def barrier():

@@ -944,6 +944,9 @@ __device__ __forceinline__ void pair_friction(const Pt& Xi, const Pt& r, const f
     }
 }
 
+#ifdef YA_BITS_TRACE
+__device__ unsigned long long* ya_bits_trace = nullptr;  // experiment: per-workgroup time stamps
+#endif
 namespace bits {
 #ifndef YA_BITS_BLOCK
 #define YA_BITS_BLOCK 64
@@ -1110,6 +1113,9 @@ __device__ __forceinline__ void pass(const Entry<Pt>* __restrict__ sh_e, const f
 // rather than a null test so that the single-GPU kernel carries neither the test nor the gather.
 template<typename Pt, Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction, bool STAGE_V = false,
     bool GLOBAL_IDS = false>
+#ifdef YA_BITS_WAVES_PER_EU
+__attribute__((amdgpu_waves_per_eu(YA_BITS_WAVES_PER_EU)))
+#endif
 __global__ __launch_bounds__(bits::BLOCK, bits::Min_waves<Pt>::value) void grid_force_bits(const int n,
     const Entry<Pt>* __restrict__ sorted, const float4* __restrict__ sorted_v,
     const int* __restrict__ cube_id, const int* __restrict__ offs, const int gs,
@@ -1151,6 +1157,10 @@ __global__ __launch_bounds__(bits::BLOCK, bits::Min_waves<Pt>::value) void grid_
     bool active = s < n;
     const int c_lo = cube_id[s0];
     const int c_hi = cube_id[min(s0 + FB, n) - 1];
+#ifdef YA_BITS_TRACE
+    unsigned long long trace_t0;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(trace_t0)::"memory");
+#endif
 
     Pt Xi = ya::zero<Pt>();
     int i = 0, c = c_lo;
@@ -1227,6 +1237,22 @@ __global__ __launch_bounds__(bits::BLOCK, bits::Min_waves<Pt>::value) void grid_
         const Pt dX = store_rhs(d_dX, i, has_gen, F, sum_v, sum_friction);
         if (d_dX_sorted) d_dX_sorted[s] = dX;  // for the sorted-space Euler stage
     }
+#ifdef YA_BITS_TRACE
+    {   // experiment: when and where this workgroup ran (ya_bits_trace: 4 words per block)
+        unsigned long long trace_t1;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(trace_t1)::"memory");
+        unsigned hw_id, xcc_id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+        if (threadIdx.x == 0 && ya_bits_trace) {
+            unsigned long long* out = ya_bits_trace + 4ull * blockIdx.x;
+            out[0] = trace_t0;
+            out[1] = trace_t1;
+            out[2] = ((unsigned long long)xcc_id << 32) | hw_id;
+            out[3] = (unsigned long long)tile;
+        }
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------

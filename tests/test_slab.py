@@ -139,6 +139,27 @@ def test_two_gloo_ranks_id_indexed_functor(oracle, tmp_path):
     assert np.abs(got["X"] - Xref).max() <= 1e-5 * scale
 
 
+def test_rccl_id_travels_through_the_rendezvous_store(tmp_path):
+    """bench.py --gpus N brings ncclUniqueId from rank 0 to the others through the store the
+    launcher serves on MASTER_PORT (NativeComm.over_store): two ranks under torch.distributed.run
+    and two started by hand (rank 0 then serves the store itself)."""
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.path.join(ROOT, "tests"))
+    worker = os.path.join(ROOT, "tests", "store_worker.py")
+    out = str(tmp_path / "torchrun")
+    proc = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                           "--master-addr", "127.0.0.1", "--master-port", "29621", worker, out],
+                          env=env, capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-2000:]
+    assert os.path.exists(out + ".0") and os.path.exists(out + ".1")
+    out = str(tmp_path / "by_hand")
+    procs = [subprocess.Popen([sys.executable, worker, out],
+                              env=dict(env, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r),
+                                       MASTER_ADDR="127.0.0.1", MASTER_PORT="29622"))
+             for r in (0, 1)]
+    assert [p.wait(timeout=600) for p in procs] == [0, 0]
+    assert os.path.exists(out + ".0") and os.path.exists(out + ".1")
+
+
 @pytest.mark.gpu
 def test_two_ranks_sharing_one_gpu_match_undivided_system(device, tmp_path):
     """The one-process-per-rank path on the device, world_size 2.  RCCL refuses two ranks on
@@ -228,6 +249,10 @@ def test_rccl_communicator_single_rank(device):
     env_keep = {k: os.environ.get(k) for k in ("RANK", "WORLD_SIZE")}
     os.environ["RANK"], os.environ["WORLD_SIZE"] = "0", "1"
     try:
+        # (a real one-rank RCCL communicator from an id, as NativeComm.over_store makes them)
+        real = slab_mod.NativeComm.from_id(slab_mod.NativeComm.unique_id(), 0, 1)
+        assert (real.rank, real.world) == (0, 1) and real.allreduce_host([3.0], take_max=True) == [3.0]
+        real.close()
         comm = slab_mod.NativeComm()
         assert (comm.rank, comm.world) == (0, 1)
         assert comm.allreduce_host([1.5, 2.0]) == [1.5, 2.0]

@@ -47,26 +47,81 @@ EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_long, C.
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int)
 
 
+COMM_ID_BYTES = 128   # YA_COMM_ID_BYTES (include/yalla_hip.h) = sizeof(ncclUniqueId)
+
+
 class NativeComm:
     """RCCL communicator of libyalla_hip.so (ya_comm_*): one per process.  With WORLD_SIZE > 1 it
     first puts the process on GPU LOCAL_RANK (one process per GPU), so create it BEFORE any
     Solution.  The unique id comes from rank 0 over TCP (RANK / WORLD_SIZE / MASTER_ADDR /
-    MASTER_PORT, as torch.distributed.run sets them): no torch.distributed needed."""
+    MASTER_PORT, as torch.distributed.run sets them): no torch.distributed needed.
+    `NativeComm.over_store()` hands the id over through the rendezvous store the launcher
+    already runs on MASTER_PORT instead (no second port)."""
 
-    def __init__(self, port_offset=1):
+    def __init__(self, port_offset=1, _handle=None):
+        lib = self._bind()
+        self._lib = lib
+        if _handle is None:
+            _handle = C.c_void_p()
+            code = lib.ya_comm_create_from_env(int(port_offset), C.byref(_handle))
+            if code != 0:
+                raise YallaError(f"ya_comm_create_from_env failed ({code})")
+        self.handle = _handle
+        self.rank, self.world = lib.ya_comm_rank(_handle), lib.ya_comm_world(_handle)
+
+    @staticmethod
+    def _bind():
         lib = _core_lib()
         lib.ya_comm_create_from_env.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        lib.ya_comm_unique_id.argtypes = [C.c_void_p]
+        lib.ya_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
         lib.ya_comm_destroy.argtypes = [C.c_void_p]
         lib.ya_comm_rank.argtypes = [C.c_void_p]
         lib.ya_comm_world.argtypes = [C.c_void_p]
         lib.ya_comm_allreduce_host.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int]
-        self._lib = lib
+        return lib
+
+    @classmethod
+    def from_id(cls, ident, rank, world):
+        """The communicator of `world` ranks from a unique id (NativeComm.unique_id() of rank 0,
+        brought here by whatever the program has: a file, MPI, a rendezvous store).  The caller
+        has put the process on its GPU."""
+        lib = cls._bind()
         handle = C.c_void_p()
-        code = lib.ya_comm_create_from_env(int(port_offset), C.byref(handle))
+        buf = C.create_string_buffer(bytes(ident), COMM_ID_BYTES)
+        code = lib.ya_comm_create(buf, int(rank), int(world), C.byref(handle))
         if code != 0:
-            raise YallaError(f"ya_comm_create_from_env failed ({code})")
-        self.handle = handle
-        self.rank, self.world = lib.ya_comm_rank(handle), lib.ya_comm_world(handle)
+            raise YallaError(f"ya_comm_create failed ({code})")
+        return cls(_handle=handle)
+
+    @classmethod
+    def unique_id(cls):
+        buf = C.create_string_buffer(COMM_ID_BYTES)
+        code = cls._bind().ya_comm_unique_id(buf)
+        if code != 0:
+            raise YallaError(f"ya_comm_unique_id failed ({code})")
+        return buf.raw
+
+    @staticmethod
+    def _id_over_store(rank, world, key, make_id):
+        import torch.distributed as dist
+        store, _, _ = next(iter(dist.rendezvous("env://", rank=rank, world_size=world)))
+        if rank == 0:
+            store.set(key, make_id())
+        return bytes(store.get(key)), store   # get() blocks until rank 0 has set the key
+
+    @classmethod
+    def over_store(cls, rank, world, key="yalla_rccl_id"):
+        """One communicator per process, the id handed over through torch.distributed's
+        rendezvous store (env://: the store torch.distributed.run serves on MASTER_PORT, or one
+        rank 0 opens there) -- no process group, no second port.  The process must already be
+        on its GPU (torch.cuda.set_device(LOCAL_RANK))."""
+        if world <= 1:
+            return cls()
+        ident, store = cls._id_over_store(rank, world, key, cls.unique_id)
+        comm = cls.from_id(ident, rank, world)
+        comm._store = store      # rank 0 may be the store's server: keep it alive with the communicator
+        return comm
 
     def allreduce_host(self, values, take_max=False):
         """Sum (or max) of a few host doubles over all ranks; blocking."""
