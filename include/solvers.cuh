@@ -1280,7 +1280,10 @@ __global__ __launch_bounds__(bits::BLOCK, bits::Min_waves<Pt>::value) void grid_
 // are those around staging.
 namespace coop {
 constexpr int BLOCK = 256;
-constexpr int MAX_HITS = 96;  // hit-list length per cell; more hits are worked off in parts
+#ifndef YA_COOP_MAX_HITS
+#define YA_COOP_MAX_HITS 96
+#endif
+constexpr int MAX_HITS = YA_COOP_MAX_HITS;  // hit-list length per cell; more hits are worked off in parts
 constexpr int STRETCH = 64;   // candidates of a row ranked at a time (<= MAX_HITS, <= 32 per lane)
 // staged cells: nine rows of (the workgroup's cells + two cubes) at rho ~ 10 per cube; wider
 // entries go plane by plane unless the workgroup is 16 cells (branching model, 32-byte entries,
