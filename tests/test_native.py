@@ -71,3 +71,28 @@ def test_one_line_declares_a_functor_stateless():
     Tile_solver at 800 pick the several-lanes-per-cell kernels by themselves -- bit-identical
     positions, >= 1.4 x / 2 x faster steps, >= 1e8 cell-updates/s at BASELINE config 2's size."""
     run("test_stateless", "ALL STATELESS TESTS PASSED")
+
+
+@pytest.mark.gpu
+def test_force_launch_trace(tmp_path):
+    """tools/micro/force_trace.hip (the force kernel built with -DYA_BITS_TRACE: every workgroup
+    stamps its start, end, CU and XCD) through tools/force_trace_summary.py: one workgroup per
+    tile, each stamped once, workgroup b on XCD b mod 8 (what xcd_contiguous_tile assumes; on a
+    repartitioned GPU this fails and the tile mapping only costs L2 locality, never results), no
+    more workgroups resident per CU than its registers hold."""
+    import json
+    import sys
+    exe = os.path.join(ROOT, "tools", "micro", "ab_bin", "force_trace")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "tools"), "micro/ab_bin/force_trace"], check=True,
+                       capture_output=True)
+    stamps = tmp_path / "stamps.csv"
+    with open(stamps, "w") as out:
+        subprocess.run([exe, "200000", "3"], stdout=out, check=True, timeout=300)
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "force_trace_summary.py"), str(stamps)],
+                          capture_output=True, text=True, check=True)
+    s = json.loads(proc.stdout)
+    assert s["cells"] == 200000 and s["workgroups"] == 3125
+    assert s["block_mod_8_is_the_xcd"]
+    assert 1 <= s["resident_workgroups_per_cu_max"] <= 24
+    assert s["mean_lifetime"] > 0 and sum(s["in_flight"]) > 0

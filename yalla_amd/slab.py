@@ -105,7 +105,10 @@ class NativeComm:
     @staticmethod
     def _id_over_store(rank, world, key, make_id):
         import torch.distributed as dist
-        store, _, _ = next(iter(dist.rendezvous("env://", rank=rank, world_size=world)))
+        from datetime import timedelta
+        # (a rank may be minutes behind the others on a fresh box: the first import of the runtime)
+        store, _, _ = next(iter(dist.rendezvous("env://", rank=rank, world_size=world,
+                                                timeout=timedelta(minutes=30))))
         if rank == 0:
             store.set(key, make_id())
         return bytes(store.get(key)), store   # get() blocks until rank 0 has set the key
