@@ -52,9 +52,26 @@ def main(path, steps, skip=0):
         busy = union([(a, b) for a, b, _ in ks]) / steps / 1e6
         force = union([(a, b) for a, b, n in ks if "grid_force" in n]) / steps / 1e6
         copies = sum(b - a for a, b, n in ks if "copyBuffer" in n or "fillBuffer" in n) / steps / 1e6
+        by_kernel = collections.defaultdict(lambda: [0, 0])
+        for a, b, n in ks:
+            short = re.sub(r"^.*?(k_\w+|grid_force_\w+?|\w+_step\w*|ghosts_into_sorted|copyBuffer|fillBuffer\w*)\b.*$", r"\1",
+                           re.sub(r"I.*$", "", n.replace("_ZN2ya15", "").replace("void ", "")) if n.startswith("_ZN2ya15")
+                           else n)
+            by_kernel[short][0] += b - a
+            by_kernel[short][1] += 1
         out["slabs"].append({"rank": r, "device_ms_per_step": busy, "force_ms_per_step": force,
-                             "copy_fill_ms_per_step": copies, "launches_per_step": len(ks) / steps})
+                             "copy_fill_ms_per_step": copies, "launches_per_step": len(ks) / steps,
+                             "kernels_us_per_step_and_launches_per_step": {
+                                 k: [round(v[0] / steps / 1e3, 1), round(v[1] / steps, 2)]
+                                 for k, v in sorted(by_kernel.items(), key=lambda kv: -kv[1][0])}})
         worst = max(worst, busy)
+    # (SLAB_TIMELINE_RANK=r: one stretch of that slab's launches -- start, duration, kernel -- on stderr)
+    import os
+    if os.environ.get("SLAB_TIMELINE_RANK"):
+        ks = per_rank[int(os.environ["SLAB_TIMELINE_RANK"])]
+        lo = len(ks) // 2
+        for a, b, n in ks[lo:lo + 140]:
+            print(f"{(a - ks[lo][0]) / 1e3:10.1f} {(b - a) / 1e3:8.1f}  {n[:70]}", file=sys.stderr)
     out["slowest_slab_device_ms_per_step"] = worst
     out["projected_speedup_device_time_only"] = out["undivided_device_ms_per_step"] / worst
     out["note"] = ("device-busy time only (no host launch gaps, no RCCL latency, no xGMI transfer time; the rehearsal's "
