@@ -2390,7 +2390,15 @@ protected:
             if (bits_kernel) {
                 part = 1;
                 if (!interior_stream) {
-                    YA_CHECK((int)hipStreamCreateWithFlags(&interior_stream, hipStreamNonBlocking));
+                    // YA_INTERIOR_LOW_PRIORITY=1: the boundary launch, whose rows the neighbours
+                    // wait for, gets the chip first.  Measured in the one-GPU rehearsal (10 M cells,
+                    // 8 slabs): the boundary rows are ready after 173-210 instead of 255 us, but the
+                    // interior launch then starts 110 us late and the stage takes 333 instead of
+                    // 312 us -- off by default until a real neighbour has been seen waiting.
+                    int least = 0, greatest = 0;
+                    YA_CHECK((int)hipDeviceGetStreamPriorityRange(&least, &greatest));
+                    YA_CHECK((int)hipStreamCreateWithPriority(&interior_stream, hipStreamNonBlocking,
+                        getenv("YA_INTERIOR_LOW_PRIORITY") ? least : 0));
                     YA_CHECK((int)hipEventCreateWithFlags(&grid_built, hipEventDisableTiming));
                     YA_CHECK((int)hipEventCreateWithFlags(&interior_done, hipEventDisableTiming));
                 }
