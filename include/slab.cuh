@@ -63,6 +63,11 @@ struct Slab_device_ops {
     {
         YA_CHECK(ya_gather_rows(src, row_bytes, idx, count, cap, dst, nullptr));
     }
+    static void gather_rows_pair(const void* src, size_t row_bytes, const int* idx0, const int* count0, void* dst0,
+        const int* idx1, const int* count1, void* dst1, int cap)
+    {
+        YA_CHECK(ya_gather_rows_pair(src, row_bytes, idx0, count0, dst0, idx1, count1, dst1, cap, nullptr));
+    }
     static void copy(void* dst, const void* src, size_t bytes)
     {
         if (bytes) YA_CHECK(ya_memcpy_d2d_async(dst, src, bytes, nullptr));

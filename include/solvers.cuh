@@ -1718,6 +1718,27 @@ __global__ __launch_bounds__(ya::UPDATE_BLOCK) void euler_step_sorted(const int 
     d_sorted[s] = e;
 }
 
+// z-slab decomposition, no generic forces: own AND mirrored cells moved inside the sorted copy
+// in one pass.  A mirrored cell (id >= n_active) has no right-hand side in sorted order -- it
+// arrived by message as row id of d_dX -- and the sorted copy holds its X[id] bit for bit, so
+// X[id] + (dX[id] - fix) dt is computed here exactly as euler_step computes it.  d_dX stays raw
+// (heun_step_raw subtracts both fixed velocities), d_X1 is not written at all.
+template<typename Pt>
+__global__ __launch_bounds__(ya::UPDATE_BLOCK) void euler_step_sorted_mirrored(const int n, const float dt,
+    const float* __restrict__ d_fix, const Pt* __restrict__ d_dX_sorted, const Pt* __restrict__ d_dX,
+    ya::Entry<Pt>* __restrict__ d_sorted, const int n_active)
+{
+    const int s = blockIdx.x * ya::UPDATE_BLOCK + threadIdx.x;
+    if (s >= n) return;
+    ya::Entry<Pt> e = d_sorted[s];
+    Pt dX = e.id >= n_active ? d_dX[e.id] : d_dX_sorted[s];
+    dX.x -= d_fix[0];
+    dX.y -= d_fix[1];
+    dX.z -= d_fix[2];
+    e.X = e.X + dX * dt;
+    d_sorted[s] = e;
+}
+
 // z-slab decomposition: the ghost cells' predictor positions arrive from the slab
 // neighbours in original order (d_X1[id], id >= n_active) and are put into the sorted
 // copy here; the own cells were moved by euler_step_sorted.
@@ -1934,6 +1955,7 @@ protected:
     float *d_mean, *d_fix, *d_mean_first, *d_fix_first, *d_workspace;
     ya_n_reader* n_reader = nullptr;
     int sorted_stage_cells = -1;  // stage API: cells in the sorted copy stage 2 may start from
+    bool mirrored_in_sorted_copy = false;  // ... and the mirrored cells' predictor is in it already
     bool fix_com = true;
     bool fix_com_z = false;
     int fix_point = 0;
@@ -1981,12 +2003,14 @@ protected:
             // stage_update(1), the ghost cells' new positions are in d_X1 (which the
             // generic forces above were given, as the reference does)
             sorted_stage_cells = -1;
-            Computer<Pt>::ghosts_in_sorted_space(n, n_active, d_X1);
+            if (!mirrored_in_sorted_copy) Computer<Pt>::ghosts_in_sorted_space(n, n_active, d_X1);
+            mirrored_in_sorted_copy = false;
             Computer<Pt>::template pwints_from_sorted<pw_int, pw_friction>(
                 n, d_dX1, n_active, has_gen);
             return;
         }
         sorted_stage_cells = -1;
+        mirrored_in_sorted_copy = false;
         const bool keep_sorted = stage == 1 && Computer<Pt>::use_sorted_pipeline();
         Computer<Pt>::template pwints<pw_int, pw_friction>(
             n, d_in, d_old_v, d_rhs, has_gen, n_active, keep_sorted);
@@ -2014,6 +2038,24 @@ protected:
         } else
             heun_step<<<blocks, ya::UPDATE_BLOCK>>>(
                 n, dt, d_dX, d_fix_velocity, d_dX1, d_X, d_old_v);
+    }
+
+    // The two updates of a z-slab's step without generic forces: stage 1 entirely inside the
+    // sorted copy (own and mirrored cells, one launch; d_dX stays raw, d_X1 is not written), stage 2
+    // with both fixed velocities subtracted in the corrector.  Returns false if stage 1 left no
+    // sorted copy to work in (a solver without the sorted pipeline): the caller then uses
+    // stage_update.
+    bool stage1_update_in_sorted_copy(int n, float dt, const float* d_fix_velocity, int n_active)
+    {
+        if (sorted_stage_cells != n) return false;
+        Computer<Pt>::predictor_in_sorted_space_mirrored(n, dt, d_fix_velocity, n_active, d_dX);
+        mirrored_in_sorted_copy = true;
+        return true;
+    }
+    void stage2_update_raw(int n, float dt, const float* d_fix_stage1, const float* d_fix_stage2)
+    {
+        heun_step_raw<<<(n + ya::UPDATE_BLOCK - 1) / ya::UPDATE_BLOCK, ya::UPDATE_BLOCK>>>(
+            n, dt, d_dX, d_fix_stage1, d_dX1, d_fix_stage2, d_X, d_old_v);
     }
 
     // Sorted-space pipeline (Grid_solver without generic forces): the predictor lives in
@@ -2145,6 +2187,7 @@ protected:
     void begin_build(const Pt*, const int*, int) {}
     void cancel_build() {}
     void predictor_in_sorted_space(int, float, const float*, int) {}
+    void predictor_in_sorted_space_mirrored(int, float, const float*, int, const Pt*) {}
     void ghosts_in_sorted_space(int, int, const Pt*) {}
     template<Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction>
     void pwints_from_sorted(int, Pt*, int, bool) {}
@@ -2481,6 +2524,12 @@ protected:
     {
         euler_step_sorted<<<(n + ya::UPDATE_BLOCK - 1) / ya::UPDATE_BLOCK, ya::UPDATE_BLOCK, 0, stream>>>(
             n, dt, d_fix, d_dX_sorted, d_sorted, n_active);
+    }
+    void predictor_in_sorted_space_mirrored(
+        const int n, const float dt, const float* d_fix, const int n_active, const Pt* d_dX)
+    {
+        euler_step_sorted_mirrored<<<(n + ya::UPDATE_BLOCK - 1) / ya::UPDATE_BLOCK, ya::UPDATE_BLOCK, 0, stream>>>(
+            n, dt, d_fix, d_dX_sorted, d_dX, d_sorted, n_active);
     }
     void ghosts_in_sorted_space(const int n, const int n_active, const Pt* d_X1)
     {

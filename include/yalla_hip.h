@@ -169,6 +169,12 @@ size_t ya_select_workspace_bytes(int n_max);
 int ya_gather_rows(const void* d_src, size_t row_bytes, const int* d_idx, const int* d_count,
     int cap, void* d_dst, void* stream);
 
+/* Two such gathers from one array in one launch: d_dst0[k] = d_src[d_idx0[k]] for
+ * k < min(*d_count0, cap), d_dst1 likewise from d_idx1 / d_count1.  A NULL index list is an empty
+ * gather.  (A z-slab packs a stage's right-hand sides for its two neighbours with it.) */
+int ya_gather_rows_pair(const void* d_src, size_t row_bytes, const int* d_idx0, const int* d_count0,
+    void* d_dst0, const int* d_idx1, const int* d_count1, void* d_dst1, int cap, void* stream);
+
 /* Appends the rows of up to two fixed-capacity messages behind the n_own rows already in
  * d_dst: first min(*d_count_lo, cap) rows of d_src_lo, then min(*d_count_hi, cap) rows of
  * d_src_hi (a NULL count = no message).  The counts are read on the device; the new total

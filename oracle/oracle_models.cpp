@@ -46,6 +46,12 @@ struct Oracle_slab_ops {
         memcpy((char*)dst + (size_t)k * row_bytes, (const char*)src + (size_t)idx[k] * row_bytes,
             row_bytes);
 }
+    static void gather_rows_pair(const void* src, size_t row_bytes, const int* idx0, const int* count0,
+    void* dst0, const int* idx1, const int* count1, void* dst1, int cap)
+{
+    if (idx0) gather_rows(src, row_bytes, idx0, count0, cap, dst0);
+    if (idx1) gather_rows(src, row_bytes, idx1, count1, cap, dst1);
+}
     static void copy(void* dst, const void* src, size_t bytes) { memmove(dst, src, bytes); }
     static int read_int(const void* d) { return *(const int*)d; }
     static void append_rows(void* dst, size_t row_bytes, int n_own, const void* lo, const void* hi,

@@ -31,6 +31,7 @@ def hip():
     lib.ya_select_workspace_bytes.restype = sz
     lib.ya_select_workspace_bytes.argtypes = [i32]
     lib.ya_gather_rows.argtypes = [vp, sz, vp, vp, i32, vp, vp]
+    lib.ya_gather_rows_pair.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, i32, vp]
     lib.ya_reduce_mean.argtypes = [vp, i32, i32, vp, vp, vp]
     lib.ya_reduce_workspace_bytes.restype = sz
     lib.ya_reduce_workspace_bytes.argtypes = [i32]
@@ -218,6 +219,28 @@ def test_select_and_gather_keep_order(hip, n):
     d_out = Dev(hip, nbytes=16 * cap)
     assert hip.ya_gather_rows(dX.p, 16, d_idx.p, d_count.p, cap, d_out.p, None) == 0
     assert np.array_equal(d_out.get(np.float32, 4 * cap).reshape(cap, 4)[:count], X[ref])
+
+
+def test_gather_rows_pair_is_two_gathers(hip):
+    """ya_gather_rows_pair against numpy: two index lists into one array in one launch, counts
+    read on the device and clamped to the capacity, a NULL list skipped."""
+    rng = np.random.default_rng(11)
+    n, cap = 50000, 7000
+    src = rng.random((n, 3), dtype=np.float32)
+    idx0 = rng.permutation(n)[:6000].astype(np.int32)
+    idx1 = rng.permutation(n)[:9000].astype(np.int32)   # longer than the capacity: clamped
+    d_src, d_i0, d_i1 = Dev(hip, src), Dev(hip, idx0), Dev(hip, idx1)
+    d_counts = Dev(hip, np.array([len(idx0), len(idx1), 0, 0], np.int32))
+    d_o0, d_o1 = Dev(hip, np.zeros((cap, 3), np.float32)), Dev(hip, np.zeros((cap, 3), np.float32))
+    assert hip.ya_gather_rows_pair(d_src.p, 12, d_i0.p, d_counts.p, d_o0.p, d_i1.p, C.c_void_p(d_counts.p.value + 4), d_o1.p,
+                                   cap, None) == 0
+    o0 = d_o0.get(np.float32, 3 * cap).reshape(cap, 3)
+    o1 = d_o1.get(np.float32, 3 * cap).reshape(cap, 3)
+    assert np.array_equal(o0[:6000], src[idx0]) and not o0[6000:].any()
+    assert np.array_equal(o1, src[idx1[:cap]])
+    d_o1b = Dev(hip, np.zeros((cap, 3), np.float32))
+    assert hip.ya_gather_rows_pair(d_src.p, 12, None, None, None, d_i1.p, C.c_void_p(d_counts.p.value + 4), d_o1b.p, cap, None) == 0
+    assert np.array_equal(d_o1b.get(np.float32, 3 * cap).reshape(cap, 3), src[idx1[:cap]])
 
 
 @pytest.mark.parametrize("n,nf", [(1, 3), (255, 3), (70000, 5), (300000, 7)])

@@ -73,6 +73,7 @@ CORE_ABI = [
     "ya_grid_build_sorted_finish", "ya_grid_rebuild_sorted", "ya_n_reader_create", "ya_n_reader_destroy",
     "ya_n_read_begin", "ya_n_read_end", "ya_grid_status", "ya_reduce_mean",
     "ya_reduce_workspace_bytes", "ya_select_z", "ya_select_workspace_bytes", "ya_gather_rows",
+    "ya_gather_rows_pair",
     "ya_append_rows", "ya_comm_unique_id", "ya_comm_create", "ya_comm_create_from_env",
     "ya_comm_destroy", "ya_comm_rank", "ya_comm_world", "ya_comm_exchange", "ya_comm_exchange_v",
     "ya_comm_allreduce_sum", "ya_comm_allreduce_host", "ya_comm_self_exchange",

@@ -1,8 +1,12 @@
 // RCCL slab-neighbour communication behind include/yalla_hip.h (ya_comm_*).
 //
 // One process per GPU.  RCCL is bound at run time (dlopen) so that libyalla_hip.so has
-// no link-time dependency on it: single-GPU programs never load it, and a process that
-// already carries an RCCL (PyTorch's) shares that copy through the common soname.
+// no link-time dependency on it: single-GPU programs never load it.  The copy that is bound is
+// the one that belongs to the HIP runtime this library itself runs on (the librccl next to the
+// loaded libamdhip64): a process may carry a second ROCm stack (PyTorch ships its own HIP, HSA
+// and RCCL), whichever was loaded first serves the `libamdhip64.so.7` soname for everyone, and
+// an RCCL of the other stack on that runtime fails in ncclCommInitRank ("unhandled cuda error":
+// seen when this library was loaded before `import torch`).
 #include <hip/hip_runtime.h>
 
 #include <arpa/inet.h>
@@ -16,6 +20,8 @@
 #include <string.h>
 #include <sys/socket.h>
 #include <unistd.h>
+
+#include <string>
 
 #include "yalla_hip.h"
 
@@ -54,10 +60,23 @@ Rccl* rccl()
 Rccl* load_rccl()
 {
     static Rccl r;
+    // first choice: beside the HIP runtime in use (by path, so that an RCCL of another stack
+    // that is already loaded under the same soname is not picked up instead)
+    Dl_info hip{};
+    if (dladdr((void*)&hipGetDeviceCount, &hip) && hip.dli_fname) {
+        const char* slash = strrchr(hip.dli_fname, '/');
+        if (slash) {
+            const std::string dir(hip.dli_fname, (size_t)(slash - hip.dli_fname + 1));
+            for (const char* name : {"librccl.so.1", "librccl.so"}) {
+                r.lib = dlopen((dir + name).c_str(), RTLD_NOW | RTLD_LOCAL);
+                if (r.lib) break;
+            }
+        }
+    }
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char* name : names) {
-        r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
         if (r.lib) break;
+        r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
     }
     if (!r.lib) {
         fprintf(stderr, "yalla-hip: cannot load RCCL (librccl.so.1): %s\n", dlerror());

@@ -417,6 +417,25 @@ __global__ __launch_bounds__(BLOCK) void k_gather_rows(const float* __restrict__
     }
 }
 
+// Two gathers from one array in one launch (a z-slab packs the rows its lower and its upper
+// neighbour wait for): dst0[k] = src[idx0[k]], k < min(*count0, cap); dst1 likewise.  A null
+// index list is an empty gather.
+__global__ __launch_bounds__(BLOCK) void k_gather_rows_pair(const float* __restrict__ src, int row_f,
+    const int* __restrict__ idx0, const int* __restrict__ count0, float* __restrict__ dst0,
+    const int* __restrict__ idx1, const int* __restrict__ count1, float* __restrict__ dst1, int cap)
+{
+    const int m0 = idx0 ? min(max(*count0, 0), cap) : 0;
+    const int m1 = idx1 ? min(max(*count1, 0), cap) : 0;
+    const long f0 = (long)m0 * row_f, total = f0 + (long)m1 * row_f;
+    for (long e = (long)blockIdx.x * BLOCK + threadIdx.x; e < total; e += (long)gridDim.x * BLOCK) {
+        const bool second = e >= f0;
+        const long r = second ? e - f0 : e;
+        const int k = (int)(r / row_f), f = (int)(r % row_f);
+        const int* idx = second ? idx1 : idx0;
+        (second ? dst1 : dst0)[r] = src[(size_t)idx[k] * row_f + f];
+    }
+}
+
 // dst rows [n_own, n_own + c_lo) = src_lo rows [0, c_lo), then c_hi rows of src_hi; the
 // counts are the first int of each message (clamped to [0, cap]); a missing message
 // counts as empty.  One thread per float.
@@ -862,6 +881,22 @@ int ya_gather_rows(const void* d_src, size_t row_bytes, const int* d_idx, const 
     if (blocks > 4096) blocks = 4096;
     k_gather_rows<<<blocks, BLOCK, 0, (hipStream_t)stream>>>(
         (const float*)d_src, row_f, d_idx, d_count, cap, (float*)d_dst);
+    return (int)hipGetLastError();
+}
+
+int ya_gather_rows_pair(const void* d_src, size_t row_bytes, const int* d_idx0, const int* d_count0,
+    void* d_dst0, const int* d_idx1, const int* d_count1, void* d_dst1, int cap, void* stream)
+{
+    if (!d_src || row_bytes < 4 || row_bytes % 4 || cap < 0 || (d_idx0 && (!d_count0 || !d_dst0)) ||
+        (d_idx1 && (!d_count1 || !d_dst1)))
+        return (int)hipErrorInvalidValue;
+    if (cap == 0 || (!d_idx0 && !d_idx1)) return 0;
+    const int row_f = (int)(row_bytes / 4);
+    long floats = ((d_idx0 ? 1L : 0L) + (d_idx1 ? 1L : 0L)) * cap * row_f;
+    int blocks = (int)((floats + BLOCK - 1) / BLOCK);
+    if (blocks > 4096) blocks = 4096;
+    k_gather_rows_pair<<<blocks, BLOCK, 0, (hipStream_t)stream>>>((const float*)d_src, row_f, d_idx0, d_count0,
+        (float*)d_dst0, d_idx1, d_count1, (float*)d_dst1, cap);
     return (int)hipGetLastError();
 }
 
