@@ -2346,8 +2346,8 @@ public:
         ya_free(d_resorted);
         ya_free(d_resorted_v);
         ya_free(d_dX_sorted);
-        if (interior_stream) {
-            (void)hipStreamDestroy(interior_stream);
+        if (interior_stream && interior_stream_owned) (void)hipStreamDestroy(interior_stream);
+        if (grid_built) {
             (void)hipEventDestroy(grid_built);
             (void)hipEventDestroy(interior_done);
         }
@@ -2384,7 +2384,18 @@ protected:
         bool has_gen = false, split = false;
     } boundary_call;
     hipStream_t interior_stream = nullptr;
+    bool interior_stream_owned = false;
     hipEvent_t grid_built = nullptr, interior_done = nullptr;
+    // The stream of a stage's second force launch, supplied by the program (several solvers of
+    // one process may share one: every stream beyond the device's few hardware queues shares a
+    // queue with another, and two launches on one queue run one after the other).  Call before
+    // the first decomposed step; the stream stays the caller's.
+    void use_interior_stream(hipStream_t s)
+    {
+        if (interior_stream && interior_stream_owned) (void)hipStreamDestroy(interior_stream);
+        interior_stream = s;
+        interior_stream_owned = false;
+    }
     // the second launch of a stage whose first one ran with force_part = 1
     template<Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction>
     void forces_interior()
@@ -2442,6 +2453,9 @@ protected:
                     YA_CHECK((int)hipDeviceGetStreamPriorityRange(&least, &greatest));
                     YA_CHECK((int)hipStreamCreateWithPriority(&interior_stream, hipStreamNonBlocking,
                         getenv("YA_INTERIOR_LOW_PRIORITY") ? least : 0));
+                    interior_stream_owned = true;
+                }
+                if (!grid_built) {
                     YA_CHECK((int)hipEventCreateWithFlags(&grid_built, hipEventDisableTiming));
                     YA_CHECK((int)hipEventCreateWithFlags(&interior_done, hipEventDisableTiming));
                 }

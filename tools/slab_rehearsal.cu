@@ -203,9 +203,17 @@ int main(int argc, char** argv)
     shared.markers = getenv("YALLA_REHEARSAL_MARKERS") != nullptr;
     std::vector<std::unique_ptr<Slab>> slabs;
     std::vector<Rank> ranks(world);
+    // One stream for every slab's interior launch (they take turns on the GPU anyway): a rank with a
+    // GPU to itself has three streams, but W slabs' own streams in this one process would share the
+    // device's four hardware queues, and a slab whose interior stream lands on the default stream's
+    // queue runs its two launches of a stage one after the other (YALLA_REHEARSAL_OWN_STREAMS=1: as
+    // rounds' earlier runs did; one slab in eight then is 5-10 % slower).
+    hipStream_t interior = nullptr;
+    if (!getenv("YALLA_REHEARSAL_OWN_STREAMS")) YA_CHECK((int)hipStreamCreateWithFlags(&interior, hipStreamNonBlocking));
     for (int r = 0; r < world; r++) {
         slabs.emplace_back(new Slab{plan.n_max, gs, 1.f});
         Slab& s = *slabs.back();
+        if (interior) s.slab_use_interior_stream(interior);
         if (s.slab_adopt(plan, r, X0.data(), n, s.h_X, s.h_n) != 0) return 2;
         s.d_global_id = nullptr;  // spring only compares i with j (as bench.py runs it)
         ranks[r].shared = &shared;
