@@ -158,6 +158,8 @@ def parse(argv=None):
                     help="attach HIP events to every this-many-th force-kernel launch (odd: both stages)")
     ap.add_argument("--sorted-pipeline", type=int, default=1,
                     help="1 = second Heun stage built from the sorted cells (default), 0 = from d_X1 (A/B)")
+    ap.add_argument("--link-order", choices=["by-first", "shuffled", "by-min"], default="by-first",
+                    help="springs_links_grid: order of the link array (default: as generated, by first cell)")
     ap.add_argument("--links-per-cell", type=int, default=3,
                     help="springs_links_grid: links from every cell to this many nearest neighbours "
                          "(protrusion-like load for Links::link_forces)")
@@ -437,6 +439,10 @@ def main(argv=None):
             _, idx = cKDTree(X).query(X, k=args.links_per_cell + 1)
             pairs = np.stack([np.repeat(np.arange(n_total), args.links_per_cell),
                               idx[:, 1:].reshape(-1)], axis=1).astype(np.int32)
+            if args.link_order == "shuffled":     # as a model's protrusions are: no order at all
+                pairs = pairs[np.random.default_rng(7).permutation(len(pairs))]
+            elif args.link_order == "by-min":     # sorted by the smaller cell id of the pair
+                pairs = pairs[np.argsort(pairs.min(axis=1), kind="stable")]
             sim.set_links(pairs, 0.2)
             n_links = len(pairs)
 
