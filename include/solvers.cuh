@@ -343,7 +343,9 @@ __device__ __forceinline__ Pt store_rhs(
         dX.y += sum_v.y / sum_friction;
         dX.z += sum_v.z / sum_friction;
     }
+#ifndef YA_AB_NO_SCATTER  /* experiment: what the 12-byte scatter by original id costs the launch */
     d_dX[i] = dX;
+#endif
     return dX;
 }
 
