@@ -30,15 +30,6 @@ __global__ void k_slab_mean_from_total(const float* total, int n_floats, float* 
     const float inv = (float)(1. / n);
     if (threadIdx.x < 3) fix[threadIdx.x] = total[threadIdx.x] * inv;
 }
-__global__ void k_slab_pack_sum(const float* sum, int n_floats, int n_own, float* out)
-{
-    if ((int)threadIdx.x < n_floats) out[threadIdx.x] = sum[threadIdx.x];
-    if ((int)threadIdx.x == n_floats) {
-        out[n_floats] = (float)(n_own & 4095);
-        out[n_floats + 1] = (float)(n_own >> 12);
-    }
-}
-
 // Backend operations of the slab logic on the device: thin wrappers over the C ABI.
 struct Slab_device_ops {
     static void* alloc(size_t bytes)
@@ -91,10 +82,6 @@ struct Slab_device_ops {
     static void mean_from_total(const float* total, int n_floats, float* fix)
     {
         k_slab_mean_from_total<<<1, 64>>>(total, n_floats, fix);
-    }
-    static void pack_sum(const float* sum, int n_floats, int n_own, float* out)
-    {
-        k_slab_pack_sum<<<1, 64>>>(sum, n_floats, n_own, out);
     }
 };
 }  // namespace ya

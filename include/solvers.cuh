@@ -1725,18 +1725,37 @@ __global__ __launch_bounds__(ya::UPDATE_BLOCK) void euler_step_sorted(const int 
 // arrived by message as row id of d_dX -- and the sorted copy holds its X[id] bit for bit, so
 // X[id] + (dX[id] - fix) dt is computed here exactly as euler_step computes it.  d_dX stays raw
 // (heun_step_raw subtracts both fixed velocities), d_X1 is not written at all.
+// The fixed velocity is taken from the stage's ALL-REDUCED totals {sum[n_floats], count in two
+// pieces} (ya_reduce_sum_packed on every rank, summed): fix = sum * float(1. / n), the reference's
+// Pt / n arithmetic (dtypes.cuh:202-217), computed by every thread alike; thread 0 leaves it in
+// d_fix_out for the corrector.
+namespace ya {
+__device__ __forceinline__ float3 fix_from_total(const float* __restrict__ total, const int n_floats)
+{
+    const double n = (double)total[n_floats] + 4096. * (double)total[n_floats + 1];
+    const float inv = (float)(1. / n);
+    return float3{total[0] * inv, total[1] * inv, total[2] * inv};
+}
+}  // namespace ya
+
 template<typename Pt>
 __global__ __launch_bounds__(ya::UPDATE_BLOCK) void euler_step_sorted_mirrored(const int n, const float dt,
-    const float* __restrict__ d_fix, const Pt* __restrict__ d_dX_sorted, const Pt* __restrict__ d_dX,
-    ya::Entry<Pt>* __restrict__ d_sorted, const int n_active)
+    const float* __restrict__ d_total, float* __restrict__ d_fix_out, const Pt* __restrict__ d_dX_sorted,
+    const Pt* __restrict__ d_dX, ya::Entry<Pt>* __restrict__ d_sorted, const int n_active)
 {
     const int s = blockIdx.x * ya::UPDATE_BLOCK + threadIdx.x;
+    const float3 fix = ya::fix_from_total(d_total, sizeof(Pt) / sizeof(float));
+    if (s == 0) {
+        d_fix_out[0] = fix.x;
+        d_fix_out[1] = fix.y;
+        d_fix_out[2] = fix.z;
+    }
     if (s >= n) return;
     ya::Entry<Pt> e = d_sorted[s];
     Pt dX = e.id >= n_active ? d_dX[e.id] : d_dX_sorted[s];
-    dX.x -= d_fix[0];
-    dX.y -= d_fix[1];
-    dX.z -= d_fix[2];
+    dX.x -= fix.x;
+    dX.y -= fix.y;
+    dX.z -= fix.z;
     e.X = e.X + dX * dt;
     d_sorted[s] = e;
 }
@@ -1770,6 +1789,33 @@ __global__ __launch_bounds__(ya::UPDATE_BLOCK) void heun_step_raw(const int n, c
     dX1.x -= d_fix1[0];
     dX1.y -= d_fix1[1];
     dX1.z -= d_fix1[2];
+    Pt X = d_X[i];
+    X += (dX + dX1) * 0.5 * dt;
+    d_X[i] = X;
+    d_old_v[i] = float3{
+        (dX.x + dX1.x) * 0.5f, (dX.y + dX1.y) * 0.5f, (dX.z + dX1.z) * 0.5f};
+}
+
+
+// heun_step_raw with the second stage's fixed velocity taken from the stage's all-reduced totals
+// (z-slab decomposition; see euler_step_sorted_mirrored).
+template<typename Pt>
+__global__ __launch_bounds__(ya::UPDATE_BLOCK) void heun_step_raw_total(const int n, const float dt,
+    const Pt* __restrict__ d_dX, const float* __restrict__ d_fix, const Pt* __restrict__ d_dX1,
+    const float* __restrict__ d_total1, Pt* __restrict__ d_X, float3* __restrict__ d_old_v)
+{
+    const int i = blockIdx.x * ya::UPDATE_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const float3 fix1 = ya::fix_from_total(d_total1, sizeof(Pt) / sizeof(float));
+
+    Pt dX = d_dX[i];
+    dX.x -= d_fix[0];
+    dX.y -= d_fix[1];
+    dX.z -= d_fix[2];
+    Pt dX1 = d_dX1[i];
+    dX1.x -= fix1.x;
+    dX1.y -= fix1.y;
+    dX1.z -= fix1.z;
     Pt X = d_X[i];
     X += (dX + dX1) * 0.5 * dt;
     d_X[i] = X;
@@ -2047,17 +2093,24 @@ protected:
     // with both fixed velocities subtracted in the corrector.  Returns false if stage 1 left no
     // sorted copy to work in (a solver without the sorted pipeline): the caller then uses
     // stage_update.
-    bool stage1_update_in_sorted_copy(int n, float dt, const float* d_fix_velocity, int n_active)
+    // (d_total: the stage's all-reduced {sum, count pieces}; stage 1 leaves its fixed velocity in
+    // d_fix_out, stage 2 reads it from there)
+    bool stage1_update_in_sorted_copy(int n, float dt, const float* d_total, float* d_fix_out, int n_active)
     {
         if (sorted_stage_cells != n) return false;
-        Computer<Pt>::predictor_in_sorted_space_mirrored(n, dt, d_fix_velocity, n_active, d_dX);
+        Computer<Pt>::predictor_in_sorted_space_mirrored(n, dt, d_total, d_fix_out, n_active, d_dX);
         mirrored_in_sorted_copy = true;
         return true;
     }
-    void stage2_update_raw(int n, float dt, const float* d_fix_stage1, const float* d_fix_stage2)
+    void stage2_update_raw(int n, float dt, const float* d_fix_stage1, const float* d_total_stage2)
     {
-        heun_step_raw<<<(n + ya::UPDATE_BLOCK - 1) / ya::UPDATE_BLOCK, ya::UPDATE_BLOCK>>>(
-            n, dt, d_dX, d_fix_stage1, d_dX1, d_fix_stage2, d_X, d_old_v);
+        heun_step_raw_total<<<(n + ya::UPDATE_BLOCK - 1) / ya::UPDATE_BLOCK, ya::UPDATE_BLOCK>>>(
+            n, dt, d_dX, d_fix_stage1, d_dX1, d_total_stage2, d_X, d_old_v);
+    }
+    // the stage's sum over the first n points as a rank puts it into the all-reduce (ya_reduce_sum_packed)
+    void stage_sum_packed(int stage, int n, float* d_out)
+    {
+        YA_CHECK(ya_reduce_sum_packed(stage == 1 ? d_dX : d_dX1, n_floats, n, d_out, d_workspace, nullptr));
     }
 
     // Sorted-space pipeline (Grid_solver without generic forces): the predictor lives in
@@ -2189,7 +2242,7 @@ protected:
     void begin_build(const Pt*, const int*, int) {}
     void cancel_build() {}
     void predictor_in_sorted_space(int, float, const float*, int) {}
-    void predictor_in_sorted_space_mirrored(int, float, const float*, int, const Pt*) {}
+    void predictor_in_sorted_space_mirrored(int, float, const float*, float*, int, const Pt*) {}
     void ghosts_in_sorted_space(int, int, const Pt*) {}
     template<Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction>
     void pwints_from_sorted(int, Pt*, int, bool) {}
@@ -2541,11 +2594,11 @@ protected:
         euler_step_sorted<<<(n + ya::UPDATE_BLOCK - 1) / ya::UPDATE_BLOCK, ya::UPDATE_BLOCK, 0, stream>>>(
             n, dt, d_fix, d_dX_sorted, d_sorted, n_active);
     }
-    void predictor_in_sorted_space_mirrored(
-        const int n, const float dt, const float* d_fix, const int n_active, const Pt* d_dX)
+    void predictor_in_sorted_space_mirrored(const int n, const float dt, const float* d_total, float* d_fix_out,
+        const int n_active, const Pt* d_dX)
     {
         euler_step_sorted_mirrored<<<(n + ya::UPDATE_BLOCK - 1) / ya::UPDATE_BLOCK, ya::UPDATE_BLOCK, 0, stream>>>(
-            n, dt, d_fix, d_dX_sorted, d_dX, d_sorted, n_active);
+            n, dt, d_total, d_fix_out, d_dX_sorted, d_dX, d_sorted, n_active);
     }
     void ghosts_in_sorted_space(const int n, const int n_active, const Pt* d_X1)
     {

@@ -29,7 +29,7 @@ extern "C" {
 /* The libraries are built with -fvisibility=hidden; only this C ABI is exported. */
 #pragma GCC visibility push(default)
 
-#define YA_ABI_VERSION 7  /* 7: + ya_gather_rows_pair */
+#define YA_ABI_VERSION 7  /* 7: + ya_gather_rows_pair, ya_reduce_sum_packed */
 
 /* Status bits reported by ya_grid_status(). */
 #define YA_STATUS_OUT_OF_GRID 1 /* a cell's cube id fell outside [0, n_cubes):
@@ -149,6 +149,12 @@ int ya_grid_status(ya_grid* g, int* bits, int clear);
  * reproducible run to run.  d_workspace must hold 1024 * n_floats floats. */
 int ya_reduce_mean(const void* d_v, int n_floats, int n, float* d_out,
     float* d_workspace, void* stream);
+
+/* The same sum in the same order, left as a rank of a z-slab decomposition puts it into a stage's
+ * all-reduce: d_out[0 .. n_floats) = the sum, d_out[n_floats] = n & 4095, d_out[n_floats + 1] = n >> 12
+ * (the cell count in two pieces that stay exact under a float sum).  d_out: n_floats + 2 floats. */
+int ya_reduce_sum_packed(const void* d_v, int n_floats, int n, float* d_out, float* d_workspace,
+    void* stream);
 
 /* Size in bytes of the workspace ya_reduce_mean needs. */
 size_t ya_reduce_workspace_bytes(int n_floats);

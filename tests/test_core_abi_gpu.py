@@ -32,6 +32,7 @@ def hip():
     lib.ya_select_workspace_bytes.argtypes = [i32]
     lib.ya_gather_rows.argtypes = [vp, sz, vp, vp, i32, vp, vp]
     lib.ya_gather_rows_pair.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, i32, vp]
+    lib.ya_reduce_sum_packed.argtypes = [vp, i32, i32, vp, vp, vp]
     lib.ya_reduce_mean.argtypes = [vp, i32, i32, vp, vp, vp]
     lib.ya_reduce_workspace_bytes.restype = sz
     lib.ya_reduce_workspace_bytes.argtypes = [i32]
@@ -219,6 +220,22 @@ def test_select_and_gather_keep_order(hip, n):
     d_out = Dev(hip, nbytes=16 * cap)
     assert hip.ya_gather_rows(dX.p, 16, d_idx.p, d_count.p, cap, d_out.p, None) == 0
     assert np.array_equal(d_out.get(np.float32, 4 * cap).reshape(cap, 4)[:count], X[ref])
+
+
+def test_reduce_sum_packed_is_the_sum_of_reduce_mean(hip):
+    """ya_reduce_sum_packed: bit for bit the sum ya_reduce_mean leaves beside its mean, followed by
+    the count in two pieces that survive a float all-reduce exactly."""
+    rng = np.random.default_rng(2)
+    for n, nf in ((1, 3), (70001, 3), (1234567, 3), (300000, 7)):
+        v = (rng.random((n, nf), dtype=np.float32) - 0.5).astype(np.float32)
+        dv = Dev(hip, v)
+        d_ws = Dev(hip, nbytes=hip.ya_reduce_workspace_bytes(nf))
+        d_a, d_b = Dev(hip, nbytes=8 * nf), Dev(hip, nbytes=4 * (nf + 2))
+        assert hip.ya_reduce_mean(dv.p, nf, n, d_a.p, d_ws.p, None) == 0
+        assert hip.ya_reduce_sum_packed(dv.p, nf, n, d_b.p, d_ws.p, None) == 0
+        a, b = d_a.get(np.float32, 2 * nf), d_b.get(np.float32, nf + 2)
+        assert np.array_equal(a[nf:].view(np.uint32), b[:nf].view(np.uint32))
+        assert b[nf] == n % 4096 and b[nf + 1] == n // 4096
 
 
 def test_gather_rows_pair_is_two_gathers(hip):

@@ -324,7 +324,10 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_partial(
     if (threadIdx.x < NW) partials[(size_t)blockIdx.x * NW + threadIdx.x] = sh[threadIdx.x * BLOCK];
 }
 
-template<int NW>
+// PACKED (z-slab decomposition): out = {sum[NW], n & 4095, n >> 12} -- what a rank puts into the
+// all-reduce of a stage: the sum over its own cells and their count in two pieces that stay exact
+// under a float sum.  Otherwise out = {mean[NW], sum[NW]}.
+template<int NW, bool PACKED = false>
 __global__ __launch_bounds__(BLOCK) void k_reduce_final(
     const float* __restrict__ partials, int n_partials, int n, float* __restrict__ out)
 {
@@ -340,9 +343,17 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_final(
     if (threadIdx.x < NW) {
         float sum = sh[threadIdx.x * BLOCK];
         // Pt / n  ==  Pt * float(1. / float(n))   (dtypes.cuh:202-217)
-        float inv = (float)(1. / (double)(float)n);
-        out[threadIdx.x] = sum * inv;
-        out[NW + threadIdx.x] = sum;
+        if (PACKED) {
+            out[threadIdx.x] = sum;
+            if (threadIdx.x == 0) {
+                out[NW] = (float)(n & 4095);
+                out[NW + 1] = (float)(n >> 12);
+            }
+        } else {
+            float inv = (float)(1. / (double)(float)n);
+            out[threadIdx.x] = sum * inv;
+            out[NW + threadIdx.x] = sum;
+        }
     }
 }
 
@@ -455,13 +466,16 @@ __global__ __launch_bounds__(BLOCK) void k_append_rows(float* __restrict__ dst, 
 }
 
 template<int NW>
-int launch_reduce(const float* v, int n, float* out, float* ws, hipStream_t st)
+int launch_reduce(const float* v, int n, float* out, float* ws, hipStream_t st, bool packed = false)
 {
     int B = ceil_div(n, BLOCK);
     if (B < 1) B = 1;
     if (B > REDUCE_MAX_BLOCKS) B = REDUCE_MAX_BLOCKS;
     k_reduce_partial<NW><<<B, BLOCK, 0, st>>>(v, n, ws);
-    k_reduce_final<NW><<<1, BLOCK, 0, st>>>(ws, B, n, out);
+    if (packed)
+        k_reduce_final<NW, true><<<1, BLOCK, 0, st>>>(ws, B, n, out);
+    else
+        k_reduce_final<NW><<<1, BLOCK, 0, st>>>(ws, B, n, out);
     return (int)hipGetLastError();
 }
 
@@ -922,14 +936,14 @@ size_t ya_reduce_workspace_bytes(int n_floats)
     return (size_t)REDUCE_MAX_BLOCKS * (size_t)n_floats * sizeof(float);
 }
 
-int ya_reduce_mean(const void* d_v, int n_floats, int n, float* d_out, float* d_ws, void* stream)
+static int reduce_any(const void* d_v, int n_floats, int n, float* d_out, float* d_ws, void* stream, bool packed)
 {
     hipStream_t st = (hipStream_t)stream;
     const float* v = (const float*)d_v;
     switch (n_floats) {
 #define YA_RED(NW) \
     case NW:       \
-        return launch_reduce<NW>(v, n, d_out, d_ws, st);
+        return launch_reduce<NW>(v, n, d_out, d_ws, st, packed);
         YA_RED(3)
         YA_RED(4)
         YA_RED(5)
@@ -948,6 +962,16 @@ int ya_reduce_mean(const void* d_v, int n_floats, int n, float* d_out, float* d_
         default:
             return (int)hipErrorInvalidValue;
     }
+}
+
+int ya_reduce_mean(const void* d_v, int n_floats, int n, float* d_out, float* d_ws, void* stream)
+{
+    return reduce_any(d_v, n_floats, n, d_out, d_ws, stream, false);
+}
+
+int ya_reduce_sum_packed(const void* d_v, int n_floats, int n, float* d_out, float* d_ws, void* stream)
+{
+    return reduce_any(d_v, n_floats, n, d_out, d_ws, stream, true);
 }
 
 }  // extern "C"
