@@ -551,6 +551,12 @@ def main(argv=None):
                              "their own 1-GPU base (one_gpu_same_system)" % MULTI_GPU_CELLS) if world == 1 else
                             "strong scaling of one %d-cell system; base = one_gpu_same_system, not the N = 1 line" % n_total,
             "vs_baseline": None,
+            # the springs workload is not stationary: see DESIGN.md section 5 and profiles/r03_springs_drift.json
+            **({"workload_note": "value is for steps %d..%d of a run started from random_sphere(%g) (40 pairs inside "
+                                 "the cut-off per cell); the springs system clumps as it runs -- 44 pairs per cell "
+                                 "after 23 steps, 73 after 63, 381 after 103 -- and a cell-update costs "
+                                 "proportionally more" % (args.warmup + 1, args.warmup + args.steps, args.dist)}
+               if args.model.startswith("springs") and state is None else {}),
             "dtype": "f32",
             "data": ("synthetic: random_sphere(%g) seed 42, glibc rand()" % args.dist) if state is None else
                     ("synthetic: the model's own set-up (yalla_amd/cases.py)" +
