@@ -322,3 +322,26 @@ def test_eight_slabs_of_a_million_cells_native_sequencing(device):
     assert par["take_steps"] == steps + warmup and par["cells_missing"] == 0
     assert par["cells_beyond_1e-5"] <= max(4, n // 2000), par
     assert par["max_abs_diff"] <= 2.0 * (steps + warmup) * dt, par
+
+
+@pytest.mark.gpu
+def test_slabs_with_a_generic_force(device):
+    """The decomposed step WITH generic forces (they read d_X1, so the step goes through the plain
+    predictor over all local cells, the mirrored cells' d_X1 copied into the sorted copy, and the
+    plain corrector -- not the sorted-copy predictor and raw corrector of the benchmarked path):
+    400 000 cells in four slabs, every cell also pulled towards the origin by a generic force
+    (tools/slab_rehearsal.cu, YALLA_REHEARSAL_GENERIC=1), against the undivided system."""
+    import json
+    exe = os.path.join(ROOT, "tools", "slab_rehearsal")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "tools"), "slab_rehearsal"], check=True, capture_output=True)
+    n, steps, warmup, dt = 400_000, 6, 2, 0.001
+    proc = subprocess.run([exe, str(n), "4", str(steps), str(warmup), "4"], capture_output=True, text=True,
+                          timeout=600, env=dict(os.environ, YALLA_REHEARSAL_GENERIC="1"))
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-2000:]
+    out = json.loads(proc.stdout.strip().splitlines()[-1])
+    assert out["world"] == 4 and out["cells_after"] == n
+    par = out["parity"]
+    assert par["take_steps"] == steps + warmup and par["cells_missing"] == 0
+    assert par["cells_beyond_1e-5"] <= max(4, n // 2000), par
+    assert par["max_abs_diff"] <= 2.0 * (steps + warmup) * dt, par

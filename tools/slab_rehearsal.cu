@@ -59,6 +59,32 @@ static void mark(int rank)
     }
 }
 
+// YALLA_REHEARSAL_GENERIC=1: every take_step (undivided and slabs) gets a generic force as well -- each
+// cell pulled towards the origin, no ids needed --, which sends the decomposed step through d_X1 and
+// the plain update kernels instead of the sorted-copy predictor and the raw corrector (a parity
+// check of that path over several slabs; not a timing configuration).
+__global__ void pull_to_origin(const int n, const float3* __restrict__ d_X, float3* d_dX)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    d_dX[i].x -= 0.3f * d_X[i].x;
+    d_dX[i].y -= 0.3f * d_X[i].y;
+    d_dX[i].z -= 0.3f * d_X[i].z;
+}
+void origin_forces(const int n, const float3* __restrict__ d_X, float3* d_dX)
+{
+    pull_to_origin<<<(n + 255) / 256, 256>>>(n, d_X, d_dX);
+}
+static bool generic_forces = false;
+template<typename Cells>
+void one_step(Cells& cells, float dt)
+{
+    if (generic_forces)
+        cells.template take_step<spring>(dt, origin_forces);
+    else
+        cells.template take_step<spring>(dt);
+}
+
 using Clock = std::chrono::steady_clock;
 using Slab = Solution<float3, Slab_grid_solver>;
 // segments of a step (a new one begins whenever a transport call returns): [re-halo: pack |
@@ -174,6 +200,7 @@ int main(int argc, char** argv)
     const int warmup = argc > 4 ? atoi(argv[4]) : 3;
     const int migrate_every = argc > 5 ? atoi(argv[5]) : 16;
     const float dt = 0.001f, dist = 0.5f;
+    generic_forces = getenv("YALLA_REHEARSAL_GENERIC") != nullptr;
     const float radius = powf(n / 0.64f, 1.f / 3) * dist / 2;
     const int gs = std::max(2 * ((int)radius + 3), 8);
 
@@ -184,10 +211,10 @@ int main(int argc, char** argv)
         Solution<float3, Grid_solver> whole{n, gs, 1.f};
         random_sphere(dist, whole, 0, 42);
         std::copy(whole.h_X, whole.h_X + n, X0.begin());
-        for (int s = 0; s < warmup; s++) whole.take_step<spring>(dt);
+        for (int s = 0; s < warmup; s++) one_step(whole, dt);
         (void)hipDeviceSynchronize();
         const auto t0 = Clock::now();
-        for (int s = 0; s < steps; s++) whole.take_step<spring>(dt);
+        for (int s = 0; s < steps; s++) one_step(whole, dt);
         (void)hipDeviceSynchronize();
         whole_ms = std::chrono::duration<double>(Clock::now() - t0).count() / steps * 1e3;
         whole.copy_to_host();  // after warmup + steps take_steps: what the slabs must reproduce
@@ -239,7 +266,7 @@ int main(int argc, char** argv)
             }
             me.segment = 0;
             me.start();
-            s.take_step<spring>(dt);
+            one_step(s, dt);
             me.stop();
             if (shared.timing) me.step_index++;
             shared.barrier.wait();
