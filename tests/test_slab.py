@@ -345,3 +345,14 @@ def test_slabs_with_a_generic_force(device):
     assert par["take_steps"] == steps + warmup and par["cells_missing"] == 0
     assert par["cells_beyond_1e-5"] <= max(4, n // 2000), par
     assert par["max_abs_diff"] <= 2.0 * (steps + warmup) * dt, par
+
+
+@pytest.mark.gpu
+def test_slabs_in_the_fast_arithmetic_tier(device):
+    """libyalla_models_fast.so (contracted multiply-adds, bare v_sqrt_f32 / v_rcp_f32) carries the
+    same decomposition: three slabs against the undivided system of the same tier."""
+    from yalla_amd import _ffi
+    fast = _ffi.device_lib("fast")
+    assert fast.ya_models_arith() == 1
+    moved = check(fast, 40000, 3, 6, 0.002, device="hip")
+    assert moved >= 0
