@@ -69,6 +69,12 @@ def test_slabs_match_undivided_system_oracle(oracle, world, n):
     check(oracle, n, world, 4, 0.002)
 
 
+def test_slabs_of_five_float_points_oracle(oracle):
+    """Po_cell (20-byte points: position + polarity) through the decomposition: messages, mirrored
+    rows and updates are sized by the point type."""
+    assert check(oracle, 3000, 3, 4, 0.002, model="relu_po_grid") >= 0
+
+
 def test_cells_migrate_between_slabs_oracle(oracle):
     moved = check(oracle, 3000, 4, 12, 0.004)
     assert moved > 0, "test too gentle: nothing crossed a slab face"
@@ -356,3 +362,10 @@ def test_slabs_in_the_fast_arithmetic_tier(device):
     assert fast.ya_models_arith() == 1
     moved = check(fast, 40000, 3, 6, 0.002, device="hip")
     assert moved >= 0
+
+
+@pytest.mark.gpu
+def test_slabs_of_five_float_points_device(device):
+    """The same on the device: 20-byte rows in the right-hand-side messages, the sorted-copy
+    predictor and the raw corrector instantiated for Po_cell."""
+    assert check(device, 40000, 3, 6, 0.002, device="hip", model="relu_po_grid") >= 0
