@@ -394,3 +394,27 @@ def test_many_lanes_per_cell_tile_kernel_bit_exact(oracle, device, model, dt):
         for X, v in res[1:]:
             assert np.array_equal(res[0][0].view(np.uint32), X.view(np.uint32)), (model, n)
             assert np.array_equal(res[0][1].view(np.uint32), v.view(np.uint32)), (model, n)
+
+
+def test_empty_and_tiny_systems(oracle, device):
+    """n = 0 (take_step returns after reading *d_n, solvers.cuh:229-230), one cell (no partner: only
+    the centre-of-mass fix acts, and it cancels the cell's own velocity), two, none again, five --
+    on both solvers, the device's grid arrays staying a permutation throughout."""
+    for model in ("springs_grid", "springs_tile"):
+        out = []
+        for lib in (oracle, device):
+            with Solution(model, 64, 20, 1.0, lib=lib) as s:
+                if lib is oracle:
+                    s.set_reduce_order(1)
+                s.random_sphere(0.5, 5)
+                snaps = []
+                for n in (0, 1, 2, 0, 5):
+                    s.copy_to_host()
+                    s.h_n = n
+                    s.copy_to_device()
+                    s.take_step(0.01, 3)
+                    assert s.get_d_n() == n
+                    snaps.append(s.positions().copy())
+                out.append(snaps)
+        for a_, b_ in zip(*out):
+            assert a_.shape == b_.shape and np.array_equal(a_.view(np.uint32), b_.view(np.uint32)), model
