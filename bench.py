@@ -228,6 +228,22 @@ def measured_counters(kernel_key):
     return out, head
 
 
+def springs_drift_note(warmup, steps, dist):
+    """The springs workload is not stationary: what the committed measurement
+    (tools/diag/springs_drift.py -> profiles/r04_springs_drift.json) says about it, or a pointer to the
+    script if that file is missing or empty."""
+    path = os.path.join(ROOT, "profiles", "r04_springs_drift.json")
+    try:
+        with open(path) as f:
+            rows = json.load(f)["rows"]
+        pairs = ", ".join("%g after %d steps" % (r["pairs_inside_cutoff_per_cell"], r["steps_taken"]) for r in rows[:6])
+        evidence = "pairs inside the cut-off per cell: %s (profiles/r04_springs_drift.json)" % pairs
+    except (OSError, ValueError, KeyError, TypeError):
+        evidence = "no measurement on file: run tools/diag/springs_drift.py"
+    return ("value is for steps %d..%d of a run started from random_sphere(%g); the springs system clumps as it "
+            "runs and a cell-update costs proportionally more -- %s" % (warmup + 1, warmup + steps, dist, evidence))
+
+
 def grid_size_for(n, dist):
     """Smallest even grid that keeps a random_sphere(dist) of n cells, radius
     (n/0.64)^(1/3) dist/2, two cubes inside the border (cube_size 1)."""
@@ -530,6 +546,12 @@ def main(argv=None):
     if rank == 0:
         value = n_total * args.steps / elapsed
         force_s = force_ms / 1e3 / max(launches, 1)
+        split_force = slab_path and world > 1
+        if split_force:
+            # a slab's stage is TWO force launches (tiles next to the faces, then all others on a stream
+            # of their own), each timed by itself and each computing only its share of the own cells:
+            # the stage's force time is at most their sum (they overlap), which is what is priced here
+            force_s *= 2
         force_bytes = force_bytes_per_cell(n_floats)
         achieved = n_force * force_bytes / force_s / 1e9 if launches else None
         key = counters_key(args, n_total)
@@ -551,11 +573,8 @@ def main(argv=None):
                              "their own 1-GPU base (one_gpu_same_system)" % MULTI_GPU_CELLS) if world == 1 else
                             "strong scaling of one %d-cell system; base = one_gpu_same_system, not the N = 1 line" % n_total,
             "vs_baseline": None,
-            # the springs workload is not stationary: see DESIGN.md section 5 and profiles/r03_springs_drift.json
-            **({"workload_note": "value is for steps %d..%d of a run started from random_sphere(%g) (40 pairs inside "
-                                 "the cut-off per cell); the springs system clumps as it runs -- 44 pairs per cell "
-                                 "after 23 steps, 73 after 63, 381 after 103 -- and a cell-update costs "
-                                 "proportionally more" % (args.warmup + 1, args.warmup + args.steps, args.dist)}
+            # the springs workload is not stationary: see DESIGN.md section 5
+            **({"workload_note": springs_drift_note(args.warmup, args.steps, args.dist)}
                if args.model.startswith("springs") and state is None else {}),
             "dtype": "f32",
             "data": ("synthetic: random_sphere(%g) seed 42, glibc rand()" % args.dist) if state is None else
@@ -590,8 +609,11 @@ def main(argv=None):
                 "traffic_head": counters_head,
                 "bytes_per_launch": n_force * force_bytes,
                 "avg_launch_us": force_s * 1e6,
+                **({"avg_launch_note": "sum of a stage's two launches (boundary tiles + all others, overlapping): an "
+                                       "upper bound of the stage's force time, so `achieved` is a lower bound"}
+                   if split_force else {}),
                 "timed_launches": launches,
-                "launches": 2 * args.steps,
+                "launches": (4 if split_force else 2) * args.steps,
                 "whole_step_achieved_GBs": step_bytes_per_cell(n_floats) * value / world / 1e9,
                 # SURVEY.md §8(d)'s second, explicitly labelled figure: bytes the reference's
                 # kernel structure requests (served here from LDS, not from HBM)

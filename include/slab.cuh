@@ -22,13 +22,17 @@
 #include "yalla_hip.h"
 
 namespace ya {
-__global__ void k_slab_mean_from_total(const float* total, int n_floats, float* fix)
+__global__ void k_slab_mean_from_total(const float* total, int n_floats, float* fix, int fix_mode)
 {
-    // fix = sum * float(1. / n): the reference's Pt / n arithmetic (dtypes.cuh:202-217); the cell
-    // count crosses the float all-reduce as two exact pieces (low 12 bits and the rest)
-    const double n = (double)total[n_floats] + 4096. * (double)total[n_floats + 1];
-    const float inv = (float)(1. / n);
-    if (threadIdx.x < 3) fix[threadIdx.x] = total[threadIdx.x] * inv;
+    // ya::fix_from_total (solvers.cuh): the mean as sum * float(1. / float(n)), the reference's Pt / n
+    // arithmetic (dtypes.cuh:202-217; the cell count crosses the float all-reduce as two exact pieces),
+    // or the fixed point's value
+    const float3 f = fix_from_total(total, n_floats, fix_mode);
+    if (threadIdx.x == 0) {
+        fix[0] = f.x;
+        fix[1] = f.y;
+        fix[2] = f.z;
+    }
 }
 // Backend operations of the slab logic on the device: thin wrappers over the C ABI.
 struct Slab_device_ops {
@@ -79,10 +83,33 @@ struct Slab_device_ops {
     }
     static void read_ints(const void* d, int k, int* out) { YA_CHECK(ya_memcpy_d2h(out, d, (size_t)k * sizeof(int))); }
     static void write_int(void* d, int v) { YA_CHECK(ya_memcpy_h2d(d, &v, sizeof(int))); }
-    static void mean_from_total(const float* total, int n_floats, float* fix)
+    static void mean_from_total(const float* total, int n_floats, float* fix, int fix_mode)
     {
-        k_slab_mean_from_total<<<1, 64>>>(total, n_floats, fix);
+        k_slab_mean_from_total<<<1, 64>>>(total, n_floats, fix, fix_mode);
     }
+    // drift guard and fixed point (include/yalla_hip.h)
+    static void copy_z(const void* X, size_t stride, int n, float* z) { YA_CHECK(ya_copy_component(X, stride, 2, n, z, nullptr)); }
+    static void find_id(const int* ids, int n, int id, int* index) { YA_CHECK(ya_find_id(ids, n, id, index, nullptr)); }
+    static int max_abs_diff(const float* a, size_t a_stride, const float* b, size_t b_stride, int n, float* partial)
+    {
+        YA_CHECK(ya_max_abs_diff(a, a_stride, b, b_stride, n, partial, nullptr));
+        return ya_max_abs_diff_partials(n);
+    }
+    static void guard_update(const float* moved, int n_moved, const float* pred, int n_pred, float limit, float lag,
+        float* state)
+    {
+        YA_CHECK(ya_slab_guard_update(moved, n_moved, pred, n_pred, limit, lag, state, nullptr));
+    }
+    // the all-reduced votes on their way to the host: queued behind the all-reduce, collected a step later
+    static void* votes_create()
+    {
+        ya_async_read* r = nullptr;
+        YA_CHECK(ya_async_read_create(2 * sizeof(float), &r));
+        return r;
+    }
+    static void votes_destroy(void* r) { (void)ya_async_read_destroy((ya_async_read*)r); }
+    static void votes_begin(void* r, const float* d_votes) { YA_CHECK(ya_async_read_begin((ya_async_read*)r, d_votes, nullptr)); }
+    static void votes_end(void* r, float* votes) { YA_CHECK(ya_async_read_end((ya_async_read*)r, votes)); }
 };
 }  // namespace ya
 

@@ -1725,39 +1725,67 @@ __global__ __launch_bounds__(ya::UPDATE_BLOCK) void euler_step_sorted(const int 
 // arrived by message as row id of d_dX -- and the sorted copy holds its X[id] bit for bit, so
 // X[id] + (dX[id] - fix) dt is computed here exactly as euler_step computes it.  d_dX stays raw
 // (heun_step_raw subtracts both fixed velocities), d_X1 is not written at all.
-// The fixed velocity is taken from the stage's ALL-REDUCED totals {sum[n_floats], count in two
-// pieces} (ya_reduce_sum_packed on every rank, summed): fix = sum * float(1. / n), the reference's
-// Pt / n arithmetic (dtypes.cuh:202-217), computed by every thread alike; thread 0 leaves it in
-// d_fix_out for the corrector.
+// The fixed velocity is taken from the stage's ALL-REDUCED totals (ya_slab_pack on every rank,
+// summed): {sum[n_floats], count in two pieces, two votes, the fixed point's right-hand side}.
+// fix_mode 0 (set_fixed()): fix = sum * float(1. / n), the reference's Pt / n arithmetic
+// (dtypes.cuh:202-217; n through binary32 as there); 1 (set_fixed(i)): the fixed point's value,
+// which only its owner put into the sum; 2 (set_fixed_xy(i), first stage): its x and y, the mean's z
+// (solvers.cuh:241-253).  Computed by every thread alike; thread 0 leaves it in d_fix_out for the
+// corrector.
 namespace ya {
-__device__ __forceinline__ float3 fix_from_total(const float* __restrict__ total, const int n_floats)
+__device__ __forceinline__ float3 fix_from_total(const float* __restrict__ total, const int n_floats, const int fix_mode = 0)
 {
     const double n = (double)total[n_floats] + 4096. * (double)total[n_floats + 1];
-    const float inv = (float)(1. / n);
-    return float3{total[0] * inv, total[1] * inv, total[2] * inv};
+    const float inv = (float)(1. / (double)(float)n);
+    const float3 mean{total[0] * inv, total[1] * inv, total[2] * inv};
+    if (fix_mode == 0) return mean;
+    const float* point = total + n_floats + 4;
+    return float3{point[0], point[1], fix_mode == 1 ? point[2] : mean.z};
+}
+// partial[blockIdx.x] = the largest v of the workgroup (v >= 0, or NaN: counted as +inf); every
+// thread of an UPDATE_BLOCK-wide workgroup must call it.  For the drift guard of a z-slab.
+__device__ __forceinline__ void block_max_to(float v, float* __restrict__ partial)
+{
+    __shared__ float sh_max[UPDATE_BLOCK / 64];
+    v = v == v ? v : INFINITY;
+    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    if ((threadIdx.x & 63) == 0) sh_max[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < UPDATE_BLOCK / 64; w++) v = fmaxf(v, sh_max[w]);
+        partial[blockIdx.x] = v;
+    }
 }
 }  // namespace ya
 
+// (pred_partial, may be NULL: per workgroup the largest |z moved by this predictor| -- the drift
+// guard of the decomposition, include/slab_logic.inc)
 template<typename Pt>
 __global__ __launch_bounds__(ya::UPDATE_BLOCK) void euler_step_sorted_mirrored(const int n, const float dt,
     const float* __restrict__ d_total, float* __restrict__ d_fix_out, const Pt* __restrict__ d_dX_sorted,
-    const Pt* __restrict__ d_dX, ya::Entry<Pt>* __restrict__ d_sorted, const int n_active)
+    const Pt* __restrict__ d_dX, ya::Entry<Pt>* __restrict__ d_sorted, const int n_active, const int fix_mode,
+    float* __restrict__ pred_partial)
 {
     const int s = blockIdx.x * ya::UPDATE_BLOCK + threadIdx.x;
-    const float3 fix = ya::fix_from_total(d_total, sizeof(Pt) / sizeof(float));
+    const float3 fix = ya::fix_from_total(d_total, sizeof(Pt) / sizeof(float), fix_mode);
     if (s == 0) {
         d_fix_out[0] = fix.x;
         d_fix_out[1] = fix.y;
         d_fix_out[2] = fix.z;
     }
-    if (s >= n) return;
-    ya::Entry<Pt> e = d_sorted[s];
-    Pt dX = e.id >= n_active ? d_dX[e.id] : d_dX_sorted[s];
-    dX.x -= fix.x;
-    dX.y -= fix.y;
-    dX.z -= fix.z;
-    e.X = e.X + dX * dt;
-    d_sorted[s] = e;
+    float moved = 0.f;
+    if (s < n) {
+        ya::Entry<Pt> e = d_sorted[s];
+        Pt dX = e.id >= n_active ? d_dX[e.id] : d_dX_sorted[s];
+        dX.x -= fix.x;
+        dX.y -= fix.y;
+        dX.z -= fix.z;
+        const float z0 = e.X.z;
+        e.X = e.X + dX * dt;
+        moved = fabsf(e.X.z - z0);
+        d_sorted[s] = e;
+    }
+    if (pred_partial) ya::block_max_to(moved, pred_partial);
 }
 
 // z-slab decomposition: the ghost cells' predictor positions arrive from the slab
@@ -1798,29 +1826,35 @@ __global__ __launch_bounds__(ya::UPDATE_BLOCK) void heun_step_raw(const int n, c
 
 
 // heun_step_raw with the second stage's fixed velocity taken from the stage's all-reduced totals
-// (z-slab decomposition; see euler_step_sorted_mirrored).
+// (z-slab decomposition; see euler_step_sorted_mirrored).  z_selected / moved_partial (may be NULL):
+// per workgroup the largest |z - z when the mirrored cells were chosen| after this update.
 template<typename Pt>
 __global__ __launch_bounds__(ya::UPDATE_BLOCK) void heun_step_raw_total(const int n, const float dt,
     const Pt* __restrict__ d_dX, const float* __restrict__ d_fix, const Pt* __restrict__ d_dX1,
-    const float* __restrict__ d_total1, Pt* __restrict__ d_X, float3* __restrict__ d_old_v)
+    const float* __restrict__ d_total1, Pt* __restrict__ d_X, float3* __restrict__ d_old_v, const int fix_mode,
+    const float* __restrict__ z_selected, float* __restrict__ moved_partial)
 {
     const int i = blockIdx.x * ya::UPDATE_BLOCK + threadIdx.x;
-    if (i >= n) return;
-    const float3 fix1 = ya::fix_from_total(d_total1, sizeof(Pt) / sizeof(float));
+    float moved = 0.f;
+    if (i < n) {
+        const float3 fix1 = ya::fix_from_total(d_total1, sizeof(Pt) / sizeof(float), fix_mode);
 
-    Pt dX = d_dX[i];
-    dX.x -= d_fix[0];
-    dX.y -= d_fix[1];
-    dX.z -= d_fix[2];
-    Pt dX1 = d_dX1[i];
-    dX1.x -= fix1.x;
-    dX1.y -= fix1.y;
-    dX1.z -= fix1.z;
-    Pt X = d_X[i];
-    X += (dX + dX1) * 0.5 * dt;
-    d_X[i] = X;
-    d_old_v[i] = float3{
-        (dX.x + dX1.x) * 0.5f, (dX.y + dX1.y) * 0.5f, (dX.z + dX1.z) * 0.5f};
+        Pt dX = d_dX[i];
+        dX.x -= d_fix[0];
+        dX.y -= d_fix[1];
+        dX.z -= d_fix[2];
+        Pt dX1 = d_dX1[i];
+        dX1.x -= fix1.x;
+        dX1.y -= fix1.y;
+        dX1.z -= fix1.z;
+        Pt X = d_X[i];
+        X += (dX + dX1) * 0.5 * dt;
+        d_X[i] = X;
+        d_old_v[i] = float3{
+            (dX.x + dX1.x) * 0.5f, (dX.y + dX1.y) * 0.5f, (dX.z + dX1.z) * 0.5f};
+        if (z_selected) moved = fabsf(X.z - z_selected[i]);
+    }
+    if (moved_partial) ya::block_max_to(moved, moved_partial);
 }
 
 
@@ -2095,22 +2129,29 @@ protected:
     // stage_update.
     // (d_total: the stage's all-reduced {sum, count pieces}; stage 1 leaves its fixed velocity in
     // d_fix_out, stage 2 reads it from there)
-    bool stage1_update_in_sorted_copy(int n, float dt, const float* d_total, float* d_fix_out, int n_active)
+    // (fix_mode: ya::fix_from_total; pred_partial / z_selected + moved_partial: the drift guard's
+    // per-workgroup maxima, (n + UPDATE_BLOCK - 1) / UPDATE_BLOCK floats each, or NULL)
+    bool stage1_update_in_sorted_copy(int n, float dt, const float* d_total, float* d_fix_out, int n_active,
+        int fix_mode = 0, float* pred_partial = nullptr)
     {
         if (sorted_stage_cells != n) return false;
-        Computer<Pt>::predictor_in_sorted_space_mirrored(n, dt, d_total, d_fix_out, n_active, d_dX);
+        Computer<Pt>::predictor_in_sorted_space_mirrored(n, dt, d_total, d_fix_out, n_active, d_dX, fix_mode, pred_partial);
         mirrored_in_sorted_copy = true;
         return true;
     }
-    void stage2_update_raw(int n, float dt, const float* d_fix_stage1, const float* d_total_stage2)
+    void stage2_update_raw(int n, float dt, const float* d_fix_stage1, const float* d_total_stage2, int fix_mode = 0,
+        const float* z_selected = nullptr, float* moved_partial = nullptr)
     {
         heun_step_raw_total<<<(n + ya::UPDATE_BLOCK - 1) / ya::UPDATE_BLOCK, ya::UPDATE_BLOCK>>>(
-            n, dt, d_dX, d_fix_stage1, d_dX1, d_total_stage2, d_X, d_old_v);
+            n, dt, d_dX, d_fix_stage1, d_dX1, d_total_stage2, d_X, d_old_v, fix_mode, z_selected, moved_partial);
     }
-    // the stage's sum over the first n points as a rank puts it into the all-reduce (ya_reduce_sum_packed)
-    void stage_sum_packed(int stage, int n, float* d_out)
+    // what a rank puts into a stage's all-reduce (ya_slab_pack): the sum over its first n points and
+    // their count, its two votes, the fixed point's right-hand side if *d_fix_index is one of its cells
+    void stage_sum_packed(int stage, int n, float* d_out, const float* d_guard_state = nullptr, int with_votes = 0,
+        int host_error = 0, const int* d_fix_index = nullptr)
     {
-        YA_CHECK(ya_reduce_sum_packed(stage == 1 ? d_dX : d_dX1, n_floats, n, d_out, d_workspace, nullptr));
+        YA_CHECK(ya_slab_pack(stage == 1 ? d_dX : d_dX1, n_floats, n, d_out, d_workspace, d_guard_state, with_votes,
+            host_error, d_fix_index, nullptr));
     }
 
     // Sorted-space pipeline (Grid_solver without generic forces): the predictor lives in
@@ -2242,7 +2283,7 @@ protected:
     void begin_build(const Pt*, const int*, int) {}
     void cancel_build() {}
     void predictor_in_sorted_space(int, float, const float*, int) {}
-    void predictor_in_sorted_space_mirrored(int, float, const float*, float*, int, const Pt*) {}
+    void predictor_in_sorted_space_mirrored(int, float, const float*, float*, int, const Pt*, int, float*) {}
     void ghosts_in_sorted_space(int, int, const Pt*) {}
     template<Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction>
     void pwints_from_sorted(int, Pt*, int, bool) {}
@@ -2340,10 +2381,19 @@ public:
             d_prev_v, n, cube_size, d_sorted, d_sorted_v, stream));
     }
     const int* offsets() const { return d_offs; }
+    // A promise that every cell's cube id lies in [cube_lo, cube_hi): builds then scan those cubes
+    // only (ya_grid_set_cube_range; a z-slab holds cells in a fraction of the grid's planes).
+    void set_cube_range(const int cube_lo, const int cube_hi) { YA_CHECK(ya_grid_set_cube_range(handle, cube_lo, cube_hi)); }
     void check_status()
     {
         int bits = 0;
         YA_CHECK(ya_grid_status(handle, &bits, 1));
+        if (bits & YA_STATUS_OUT_OF_RANGE) {
+            fprintf(stderr,
+                "yalla-hip: a cell left the cube range its z-slab promised the grid (Grid::set_cube_range): it "
+                "moved more than a cube between two selections of the mirrored cells.\n");
+            abort();
+        }
         if (bits & YA_STATUS_OUT_OF_GRID) {
             fprintf(stderr,
                 "yalla-hip: a cell left the %d^3 grid (device assertion at "
@@ -2595,10 +2645,10 @@ protected:
             n, dt, d_fix, d_dX_sorted, d_sorted, n_active);
     }
     void predictor_in_sorted_space_mirrored(const int n, const float dt, const float* d_total, float* d_fix_out,
-        const int n_active, const Pt* d_dX)
+        const int n_active, const Pt* d_dX, const int fix_mode, float* pred_partial)
     {
         euler_step_sorted_mirrored<<<(n + ya::UPDATE_BLOCK - 1) / ya::UPDATE_BLOCK, ya::UPDATE_BLOCK, 0, stream>>>(
-            n, dt, d_total, d_fix_out, d_dX_sorted, d_dX, d_sorted, n_active);
+            n, dt, d_total, d_fix_out, d_dX_sorted, d_dX, d_sorted, n_active, fix_mode, pred_partial);
     }
     void ghosts_in_sorted_space(const int n, const int n_active, const Pt* d_X1)
     {

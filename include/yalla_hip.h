@@ -29,12 +29,15 @@ extern "C" {
 /* The libraries are built with -fvisibility=hidden; only this C ABI is exported. */
 #pragma GCC visibility push(default)
 
-#define YA_ABI_VERSION 7  /* 7: + ya_gather_rows_pair, ya_reduce_sum_packed */
+#define YA_ABI_VERSION 8  /* 8: + ya_grid_set_cube_range, YA_STATUS_OUT_OF_RANGE, the slab guard / fixed point / payload entries, ya_async_read_* */
 
 /* Status bits reported by ya_grid_status(). */
 #define YA_STATUS_OUT_OF_GRID 1 /* a cell's cube id fell outside [0, n_cubes):
                                    the reference's D_ASSERT at
                                    solvers.cuh:361-362 */
+
+#define YA_STATUS_OUT_OF_RANGE 2 /* a cell's cube id fell outside the range promised to
+                                    ya_grid_set_cube_range */
 
 int ya_abi_version(void);
 
@@ -134,6 +137,19 @@ int ya_grid_rebuild_sorted(ya_grid* g, const void* d_prev_sorted, size_t entry_b
     size_t point_bytes, const void* d_prev_sorted_v, int n, float cube_size, void* d_sorted_out,
     void* d_sorted_v_out, void* stream);
 
+/* A promise about where cells can be: every cell's cube id lies in [cube_lo, cube_hi).  Builds
+ * then run their prefix sum (k_tile_sum, k_scan: 16 bytes written per cube of the grid, whatever
+ * it holds) over the scan tiles of that range only -- once one build with the same cell count has
+ * scanned the whole grid, which leaves offs[] = 0 / n and the -1 / -2 sentinels of cube_start /
+ * cube_end below and above the range; a build with another count, or through
+ * ya_grid_build_sorted_begin, scans everything again.  A z-slab of a decomposed system holds cells
+ * in an eighth of the grid's planes (include/slab_logic.inc sets the range from its faces); the
+ * full scan is 2 x 15 us of its 0.9 ms step at 10 M cells in 8 slabs.  A cell outside the range
+ * raises YA_STATUS_OUT_OF_RANGE and is binned into the range's first or last cube (memory-safe,
+ * like a cell outside the grid).  (0, n_cubes) or wider removes the promise.  New relative to the
+ * reference (single GPU: its two thrust::fill of gs^3 ints per build, solvers.cuh:409-412). */
+int ya_grid_set_cube_range(ya_grid* g, int cube_lo, int cube_hi);
+
 /* Sticky status bits (YA_STATUS_*); blocking 4-byte read.  `clear` != 0
  * resets them. */
 int ya_grid_status(ya_grid* g, int* bits, int clear);
@@ -189,6 +205,44 @@ int ya_gather_rows_pair(const void* d_src, size_t row_bytes, const int* d_idx0, 
 int ya_append_rows(void* d_dst, size_t row_bytes, int n_own, const void* d_src_lo,
     const int* d_count_lo, const void* d_src_hi, const int* d_count_hi, int cap, int* d_n_out,
     void* stream);
+
+/* ---- z-slab decomposition: drift guard, fixed point, a stage's all-reduce payload ---------- */
+
+/* d_dst[i] = float number `component` of row i of d_src (rows of stride_bytes): a slab keeps the z
+ * of its own and mirrored cells at the moment the mirrored cells were chosen. */
+int ya_copy_component(const void* d_src, size_t stride_bytes, int component, int n, float* d_dst, void* stream);
+/* *d_index = the position of `id` in d_ids[0 .. n) (unique ids), or -1: which local cell is the
+ * fixed point of set_fixed(i) / set_fixed_xy(i) (solvers.cuh:197-208), if this rank owns it. */
+int ya_find_id(const int* d_ids, int n, int id, int* d_index, void* stream);
+/* d_partial[b] = max over block b's share of |d_a[i] - d_b[i]|, i < n (element strides in bytes; a NaN
+ * counts as +inf); ya_max_abs_diff_partials(n) <= 1024 partials are written. */
+int ya_max_abs_diff(const float* d_a, size_t a_stride_bytes, const float* d_b, size_t b_stride_bytes, int n,
+    float* d_partial, void* stream);
+int ya_max_abs_diff_partials(int n);
+/* The drift guard between a step's two stages.  d_state = {moved, predicted, request, error}: moved =
+ * max of the n_moved partials (|z - z at selection| as the previous step left the cells), predicted =
+ * max of the n_pred partials (this step's predictor |dz|); error (sticky) if moved + predicted exceeds
+ * `limit` (the second stage would compute with it), request if moved + lag_steps * predicted does.
+ * (A z-slab's mirrored cells are valid only while no cell has moved further than
+ * (halo - cube_size) / 2 since they were chosen; include/slab_logic.inc.) */
+int ya_slab_guard_update(const float* d_moved_partial, int n_moved, const float* d_pred_partial, int n_pred,
+    float limit, float lag_steps, float* d_state, void* stream);
+/* ya_reduce_sum_packed plus what else a rank puts into a stage's all-reduce: d_out[n_floats + 2] = its
+ * vote for an early re-selection and [n_floats + 3] = its error vote (d_guard_state[2], [3] if
+ * with_votes, plus 1 if host_error), [n_floats + 4 .. + 6] = x, y, z of row *d_fix_index of d_v (the
+ * fixed point's right-hand side, solvers.cuh:250-253,269-272) or zeros if that index is negative or
+ * the pointer NULL, [n_floats + 7] = 0.  d_out: n_floats + 8 floats. */
+int ya_slab_pack(const void* d_v, int n_floats, int n, float* d_out, float* d_ws, const float* d_guard_state,
+    int with_votes, int host_error, const int* d_fix_index, void* stream);
+
+/* `bytes` (<= 4096) read back without stalling the stream that produces them: _begin queues the copy
+ * into pinned memory behind everything already in `stream`, _end waits for it (ya_n_reader for any
+ * small record: the all-reduced votes of a z-slab step are collected one step later). */
+typedef struct ya_async_read ya_async_read;
+int ya_async_read_create(size_t bytes, ya_async_read** out);
+int ya_async_read_destroy(ya_async_read* r);
+int ya_async_read_begin(ya_async_read* r, const void* d_src, void* stream);
+int ya_async_read_end(ya_async_read* r, void* h_out);
 
 /* ---- Slab neighbours over RCCL (multi-GPU, one process per GPU) ------------- */
 

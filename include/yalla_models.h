@@ -105,12 +105,21 @@ int ya_sim_set_links(ya_sim* sim, const int* ab, int n_links, float strength);
  *                     the grid over own + mirrored cells, the forces of the tiles next to the
  *                     faces, ONE message per neighbour -- the right-hand sides dX of the cells it
  *                     mirrors, at their exact length, travelling beside the forces of all other
- *                     tiles --, the all-reduce of {sum dX, cell count} (n_floats + 2 floats: the
- *                     count in two pieces that stay exact under a float sum) and the update of
- *                     own and mirrored cells; if `migrate`, the cells that left the slab are
- *                     handed over afterwards and the next step chooses the mirrored cells anew.
- *                     Between two migrations no cell may drift further than (halo_width -
- *                     cube_size) / 2.
+ *                     tiles --, the all-reduce of {sum dX, cell count, votes, the fixed point's
+ *                     right-hand side} (n_floats + 8 floats: the count in two pieces that stay
+ *                     exact under a float sum) and the update of own and mirrored cells; if
+ *                     `migrate` -- or if the drift guard asked for it --, the cells that left the
+ *                     slab are handed over afterwards and the next step chooses the mirrored
+ *                     cells anew.  Between two selections no cell may drift further than
+ *                     (halo_width - cube_size) / 2: the guard measures it every step, votes for an
+ *                     early selection through the all-reduce, and stops ALL ranks in the same
+ *                     step (-11 on the rank whose cell went too far, -12 on the others) if the
+ *                     bound was broken all the same.  set_fixed(), set_fixed(i) and
+ *                     set_fixed_xy(i) (i: a global id) all work: the owner of cell i contributes
+ *                     its right-hand side to the all-reduce.
+ *   ya_slab_info      what = 0: selections of the mirrored cells so far, 1: those the drift
+ *                     guard asked for, 2: this rank's sticky failure code (0: none), 3 / 4: the guard's
+ *                     moved / predicted distances of the last step in millionths of a length unit
  * exchange callback: `kind` 0 = mirrored cells' state and 1 = migrating cells (both fixed
  * capacity, 16-byte header {int count} + rows), 2 = a stage's right-hand sides (bare rows);
  * send_*_bytes from the send buffers to the lower / upper neighbour, recv_*_bytes from them into
@@ -124,6 +133,7 @@ int ya_slab_setup(ya_sim* sim, int rank, int world, int halo_cap_cells, int migr
 int ya_slab_set_transport(ya_sim* sim, ya_slab_exchange_fn exchange, ya_slab_allreduce_fn allreduce, void* ctx);
 int ya_slab_use_rccl(ya_sim* sim, void* comm);
 int ya_slab_step(ya_sim* sim, float dt, int migrate);
+long ya_slab_info(ya_sim* sim, int what);
 int ya_slab_n_own(ya_sim* sim);
 /* own + mirrored cells as of the last step */
 int ya_slab_n_local(ya_sim* sim);

@@ -71,12 +71,67 @@ struct Oracle_slab_ops {
     static void write_int(void* d, int v) { *(int*)d = v; }
 // The cell count travels through the float all-reduce as two exact pieces (low 12 bits and
 // the rest): exact for any total below 2^36 however many ranks add up.
-    static void mean_from_total(const float* total, int n_floats, float* fix)
+// fix_mode 0: the mean, sum * float(1. / float(n)) (the reference's Pt / n, dtypes.cuh:202-217);
+// 1: the fixed point's right-hand side (total[n_floats + 4 ..]), 2: its x and y, the mean's z
+// (solvers.cuh:241-253)
+    static void mean_from_total(const float* total, int n_floats, float* fix, int fix_mode)
 {
     const double n = (double)total[n_floats] + 4096. * (double)total[n_floats + 1];
-    const float inv = (float)(1. / n);
+    const float inv = (float)(1. / (double)(float)n);
     for (int k = 0; k < 3; k++) fix[k] = total[k] * inv;
+    if (fix_mode == 0) return;
+    const float* point = total + n_floats + 4;
+    fix[0] = point[0];
+    fix[1] = point[1];
+    if (fix_mode == 1) fix[2] = point[2];
 }
+// votes and the fixed point's right-hand side behind the packed sum (ya_slab_pack on the device)
+    static void pack_extra(const float* rhs, int n_floats, const float* guard_state, int with_votes,
+    int host_error, const int* fix_index, float* out)
+{
+    out[n_floats + 2] = with_votes ? guard_state[2] : 0.f;
+    out[n_floats + 3] = (with_votes ? guard_state[3] : 0.f) + (host_error ? 1.f : 0.f);
+    const int f = fix_index ? *fix_index : -1;
+    for (int k = 0; k < 3; k++) out[n_floats + 4 + k] = f >= 0 ? rhs[(size_t)f * n_floats + k] : 0.f;
+    out[n_floats + 7] = 0.f;
+}
+    static void copy_z(const void* X, size_t stride, int n, float* z)
+{
+    for (int i = 0; i < n; i++) z[i] = *(const float*)((const char*)X + (size_t)i * stride + 8);
+}
+    static void find_id(const int* ids, int n, int id, int* index)
+{
+    *index = -1;
+    for (int i = 0; i < n; i++)
+        if (ids[i] == id) *index = i;
+}
+    static int max_abs_diff(const float* a, size_t a_stride, const float* b, size_t b_stride, int n, float* partial)
+{
+    float m = 0.f;
+    for (int i = 0; i < n; i++) {
+        const float d = fabsf(*(const float*)((const char*)a + (size_t)i * a_stride) -
+                              *(const float*)((const char*)b + (size_t)i * b_stride));
+        m = d == d ? fmaxf(m, d) : INFINITY;
+    }
+    partial[0] = m;
+    return 1;
+}
+// the drift guard's bookkeeping (ya_slab_guard_update, yalla_amd/csrc/core.hip k_slab_guard)
+    static void guard_update(const float* moved, int n_moved, const float* pred, int n_pred, float limit, float lag,
+    float* state)
+{
+    float a = 0.f, p = 0.f;
+    for (int k = 0; k < n_moved; k++) a = fmaxf(a, moved[k]);
+    for (int k = 0; k < n_pred; k++) p = fmaxf(p, pred[k]);
+    state[0] = a;
+    state[1] = p;
+    state[2] = !(a + lag * p <= limit) ? 1.f : 0.f;
+    state[3] = !(a + p <= limit) ? 1.f : state[3];
+}
+    static void* votes_create() { return calloc(2, sizeof(float)); }
+    static void votes_destroy(void* r) { free(r); }
+    static void votes_begin(void* r, const float* votes) { memcpy(r, votes, 2 * sizeof(float)); }
+    static void votes_end(void* r, float* votes) { memcpy(votes, r, 2 * sizeof(float)); }
     static void pack_sum(const float* sum, int n_floats, int n_own, float* out)
 {
     for (int k = 0; k < n_floats; k++) out[k] = sum[k];

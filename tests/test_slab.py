@@ -92,13 +92,28 @@ def test_slabs_thinner_than_the_ghost_layer_are_refused(oracle):
         slab_mod.slab_plan(X0, 6, 1.0, oracle)
 
 
-def test_native_plan_is_the_quantile_plan(oracle):
-    """ya::slab_plan through the C ABI: cut planes = z-quantiles (equal cell counts), capacities
-    from the fullest ghost layer."""
+def test_native_plan_cuts_on_cube_planes_and_balances_own_plus_mirrored_cells(oracle):
+    """ya::slab_plan through the C ABI against its numpy restatement: cut planes on cube-plane
+    boundaries, the largest own + 0.6 * mirrored count of a slab as small as such cuts allow,
+    capacities from the fullest ghost layer."""
     X0, _ = reference_run(oracle, 5000, 50, 0.5, 3, 0.001, 0)
     bounds, halo_cap, mig_cap, n_max = slab_mod.slab_plan(X0, 4, 1.0, oracle)
     assert np.array_equal(bounds, slab_mod.slab_bounds(X0[:, 2], 4))
+    assert np.array_equal(bounds[1:-1], np.round(bounds[1:-1])), "cuts are not on cube-plane boundaries"
     z = X0[:, 2]
+
+    def worst(b):  # what the plan minimises
+        costs = []
+        for r in range(4):
+            own = np.count_nonzero((z >= b[r]) & (z < b[r + 1]))
+            ghosts = (np.count_nonzero((z >= b[r] - 1.25) & (z < b[r])) if r > 0 else 0) + \
+                     (np.count_nonzero((z >= b[r + 1]) & (z < b[r + 1] + 1.25)) if r < 3 else 0)
+            costs.append(own + 0.6 * ghosts)
+        return max(costs)
+
+    # the balance is within a plane of cells of what the quantile cuts (which may lie anywhere) reach
+    planes_cells = np.bincount((np.floor(z) - np.floor(z).min()).astype(int)).max()
+    assert worst(bounds) <= worst(slab_mod.slab_bounds(z, 4, snap_to_planes=False)) + planes_cells
     fullest = max(max(np.count_nonzero((z >= f - 1.25) & (z < f)), np.count_nonzero((z >= f) & (z < f + 1.25)))
                   for f in bounds[1:-1])
     assert halo_cap == int(fullest * 1.15) + 64 and mig_cap == halo_cap // 4 + 64
@@ -113,6 +128,126 @@ def test_id_indexed_functor_in_slabs_oracle(oracle):
     for world in (2, 3):
         moved = check(oracle, 3000, world, 6, 0.002, model="sorting_grid")
         assert moved >= 0
+
+
+def test_drift_guard_reselects_the_mirrored_cells_early_oracle(oracle):
+    """The caller never asks for a migration (as a model with a too large migrate_every would): the
+    drift guard measures how far cells have moved since the mirrored cells were chosen, votes through
+    the all-reduce and makes every rank migrate and re-select in the same step -- the run stays within
+    1e-5 of the undivided system.  (Rounds 1-3 stepped on silently with a stale selection.)"""
+    n, dt, steps = 3000, 0.0005, 30
+    X0, Xref = reference_run(oracle, n, 50, 0.5, 3, dt, steps)
+    plan = slab_mod.slab_plan(X0, 3, 1.0, oracle)
+    slabs = [slab_mod.Slab("springs_grid", X0, r, 3, 50, lib=oracle, plan=plan) for r in range(3)]
+    slab_mod.run_slabs(slabs, dt, steps, migrate_every=10 ** 9)
+    infos = [s.info() for s in slabs]
+    assert len(set(infos)) == 1, "ranks disagree about the selections they made"
+    selections, by_guard, failed = infos[0]
+    assert by_guard >= 1 and selections == by_guard + 1 and failed == 0
+    X = np.zeros_like(X0)
+    for s in slabs:
+        gid, Xr = s.own_cells()
+        X[gid] = Xr
+        moved, predicted = s.guard_state()
+        assert moved + predicted <= 0.125
+        s.close()
+    assert np.abs(X - Xref).max() <= 1e-5 * np.abs(Xref).max()
+
+
+def test_drift_beyond_the_bound_stops_every_rank_in_the_same_step_oracle(oracle):
+    """A step so violent that cells move further than (halo - cube_size) / 2 = 1/8 cube at once: no
+    vote can act in time, the bound IS broken -- and every rank leaves the same step with an error
+    (-11 where a cell went too far, -12 elsewhere) instead of computing on."""
+    n, dt = 3000, 0.05
+    X0, _ = reference_run(oracle, n, 50, 0.5, 3, dt, 0)
+    plan = slab_mod.slab_plan(X0, 3, 1.0, oracle)
+    slabs = [slab_mod.Slab("springs_grid", X0, r, 3, 50, lib=oracle, plan=plan) for r in range(3)]
+    taken = [0, 0, 0]
+    shared = slab_mod.ThreadTransport.Shared(3, False)
+    for r, s in enumerate(slabs):
+        s.use(transport=slab_mod.ThreadTransport(shared, r))
+    codes = [None] * 3
+
+    def work(r):
+        try:
+            for _ in range(6):
+                slabs[r].step(dt, migrate=False)
+                taken[r] += 1
+        except slab_mod.YallaError as err:
+            codes[r] = err.code
+
+    import threading
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert all(c in (-11, -12) for c in codes) and -11 in codes, codes
+    assert len(set(taken)) == 1, f"ranks stopped in different steps: {taken}"
+    # with the guard switched off the same run steps on (what rounds 1-3 did)
+    for s in slabs:
+        s.close()
+
+
+@pytest.mark.parametrize("mode", ["point", "point_xy"])
+def test_fixed_points_in_slabs_oracle(oracle, mode):
+    """set_fixed(i) / set_fixed_xy(i) (solvers.cuh:197-208) in a decomposed system: the rank that owns
+    cell i contributes its right-hand side to the stage's all-reduce, every rank subtracts it (xy: its
+    x and y with the mean's z in the first stage, the point's value in the second, as the reference
+    does).  i is a GLOBAL id; the cell changes owner during the run."""
+    n, dt, steps, world = 3000, 0.002, 8, 3
+    X0, _ = reference_run(oracle, n, 50, 0.5, 3, dt, 0)
+    bounds = slab_mod.slab_plan(X0, world, 1.0, oracle)[0]
+    # a cell just below the first cut plane: it is likely to cross it
+    z = X0[:, 2]
+    point = int(np.argmin(np.where(z < bounds[1], bounds[1] - z, np.inf)))
+    with Solution("springs_grid", n, 50, 1.0, lib=oracle) as ref:
+        ref.h_X[:n] = X0
+        ref.copy_to_device()
+        ref.set_fixed(point) if mode == "point" else ref.set_fixed_xy(point)
+        ref.take_step(dt, steps)
+        Xref = ref.positions()
+    assert np.abs(Xref[point] - X0[point])[:2].max() < 1e-6, "the reference run did not hold the point"
+    plan = slab_mod.slab_plan(X0, world, 1.0, oracle)
+    slabs = [slab_mod.Slab("springs_grid", X0, r, world, 50, lib=oracle, plan=plan) for r in range(world)]
+    for s in slabs:
+        s.sim.set_fixed(point) if mode == "point" else s.sim.set_fixed_xy(point)
+    slab_mod.run_slabs(slabs, dt, steps, migrate_every=2)
+    X = np.zeros_like(X0)
+    for s in slabs:
+        gid, Xr = s.own_cells()
+        X[gid] = Xr
+        s.close()
+    assert np.abs(X - Xref).max() <= 1e-5 * np.abs(Xref).max()
+
+
+def test_a_failing_rank_takes_the_others_with_it_oracle(oracle):
+    """Message capacities far too small for the ghost layers (-4 on the ranks that receive them): the
+    failing ranks keep stepping memory-safely until their error vote has been all-reduced, and ALL
+    ranks return from that same first step -- nobody is left waiting in a collective."""
+    n, world = 3000, 3
+    X0, _ = reference_run(oracle, n, 50, 0.5, 3, 0.001, 0)
+    bounds, halo_cap, mig_cap, n_max = slab_mod.slab_plan(X0, world, 1.0, oracle)
+    slabs = []
+    for r in range(world):
+        own = np.flatnonzero((X0[:, 2] >= bounds[r]) & (X0[:, 2] < bounds[r + 1])).astype(np.int32)
+        sim = Solution("springs_grid", n_max, 50, 1.0, lib=oracle)
+        sim.h_X[:len(own)] = X0[own]
+        sim.h_n = len(own)
+        sim.copy_to_device()
+        import ctypes as C
+        assert oracle.ya_slab_init(sim._h, float(bounds[r]), float(bounds[r + 1]), 1.25,
+                                   own.ctypes.data_as(C.POINTER(C.c_int))) == 0
+        assert oracle.ya_slab_setup(sim._h, r, world, 16, 16) == 0   # 16 cells where hundreds are needed
+        sl = slab_mod.Slab.__new__(slab_mod.Slab)
+        sl.rank, sl.world, sl.sim, sl._lib, sl._h, sl._transport, sl.n_floats = r, world, sim, oracle, sim._h, None, 3
+        slabs.append(sl)
+    with pytest.raises(slab_mod.YallaError) as raised:
+        slab_mod.run_slabs(slabs, 0.001, 3, migrate_every=1)
+    codes = raised.value.all_codes
+    assert len(codes) == world and all(c in (-4, -12) for c in codes) and -4 in codes, codes
+    for s in slabs:
+        s.close()
 
 
 def run_ranks(tmp_path, name, port, *worker_args):
@@ -322,7 +457,7 @@ def test_eight_slabs_of_a_million_cells_native_sequencing(device):
     assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-2000:]
     out = json.loads(proc.stdout.strip().splitlines()[-1])
     assert out["world"] == 8 and len(out["slabs"]) == 8 and out["cells_after"] == n
-    assert min(s["n_own"] for s in out["slabs"]) > 0.9 * n / 8
+    assert min(s["n_own"] for s in out["slabs"]) > 0.7 * n / 8   # (cuts balance own + 0.6 mirrored cells)
     assert all(s["n_ghost"] > 0 for s in out["slabs"])
     par = out["parity"]
     assert par["take_steps"] == steps + warmup and par["cells_missing"] == 0

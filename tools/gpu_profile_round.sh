@@ -5,7 +5,7 @@
 # passes (traffic: FETCH_SIZE and WRITE_SIZE in separate passes; SQ / cache counters).
 # The counters' summary (tools/roofline_json.py -> $out/counters.json, one entry) is made on the box and
 # the raw per-dispatch CSVs are dropped there: gpurun carries at most 64 MiB back.
-tag=${1:-round}; key=${2:-none}; head=${3:-unknown}; shift 3
+tag=${1:-round}; key=${2:-none}; head=${3:-unknown}; shift $(( $# < 3 ? $# : 3 ))
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag; mkdir -p $out
 cd $GRAFT_REPO_ROOT
 state=""

@@ -252,6 +252,8 @@ int main(int argc, char** argv)
     X0.shrink_to_fit();
 
     std::vector<int> ghosts(world, 0), owns(world, 0);
+    std::vector<long> selections(world, 0), guard_requests(world, 0);
+    std::vector<float> guard_moved(world, 0.f), guard_predicted(world, 0.f);
     // every cell's position after the run, by global id, for the comparison with the undivided system
     std::vector<float3> X_slabs((size_t)n, float3{NAN, NAN, NAN});
     std::mutex collect;
@@ -273,6 +275,14 @@ int main(int argc, char** argv)
         }
         ghosts[r] = s.slab.ghosts[0] + s.slab.ghosts[1];
         owns[r] = s.slab.n_own;
+        selections[r] = s.slab.rehalos;
+        guard_requests[r] = s.slab.guard_requests;
+        if (s.slab.d_guard) {
+            float state[4] = {0, 0, 0, 0};
+            (void)hipMemcpy(state, s.slab.d_guard, sizeof(state), hipMemcpyDeviceToHost);
+            guard_moved[r] = state[0];
+            guard_predicted[r] = state[1];
+        }
         std::lock_guard<std::mutex> lock(collect);
         std::vector<float> X((size_t)3 * plan.n_max);
         std::vector<int> gid((size_t)plan.n_max);
@@ -326,10 +336,10 @@ int main(int argc, char** argv)
         critical += seg_max[g];
         critical_mean += mean_max;
     }
-    printf("{\"cells\": %d, \"world\": %d, \"grid_size\": %d, \"steps\": %d, \"warmup\": %d, \"migrate_every\": %d, "
+    printf("{\"cells\": %d, \"world\": %d, \"grid_size\": %d, \"steps\": %d, \"warmup\": %d, \"migrate_every\": %d, \"cuts_on_cube_planes\": %s, "
            "\"sequencing\": \"native (Slab_grid_solver::take_step), one host thread per slab, slabs take turns on the GPU\", "
            "\"undivided_ms_per_step\": %.4f, \"halo_cap\": %d, \"slabs\": [",
-        n, world, gs, steps, warmup, migrate_every, whole_ms, plan.halo_cap);
+        n, world, gs, steps, warmup, migrate_every, plan.snapped ? "true" : "false", whole_ms, plan.halo_cap);
     long total_own = 0;
     for (int r = 0; r < world; r++) {
         double sum = 0;
@@ -337,8 +347,10 @@ int main(int argc, char** argv)
         slowest_slab = std::max(slowest_slab, slab_median[r] * steps);
         total_own += owns[r];
         printf("%s{\"rank\": %d, \"n_own\": %d, \"n_ghost\": %d, \"ms_per_step_median\": %.4f, \"ms_per_step_mean\": %.4f, "
-               "\"rhs_message_bytes_per_stage\": %.0f, \"segments_ms_mean\": [", r ? ", " : "", r, owns[r], ghosts[r],
-            slab_median[r] * 1e3, sum / steps * 1e3, (double)ranks[r].message_bytes / (2.0 * steps));
+               "\"rhs_message_bytes_per_stage\": %.0f, \"selections_of_mirrored_cells\": %ld, \"asked_for_by_drift_guard\": %ld, "
+               "\"guard_moved\": %.4f, \"guard_predicted\": %.4f, \"segments_ms_mean\": [", r ? ", " : "", r, owns[r], ghosts[r],
+            slab_median[r] * 1e3, sum / steps * 1e3, (double)ranks[r].message_bytes / (2.0 * steps), selections[r], guard_requests[r],
+            guard_moved[r], guard_predicted[r]);
         for (int g = 0; g < SEGMENTS; g++) printf("%s%.4f", g ? ", " : "", ranks[r].seconds[g] / steps * 1e3);
         printf("]}");
     }

@@ -49,6 +49,7 @@ MODELS_ABI = {
     "ya_sim_set_links": (C.c_int, [_sim, _pi, C.c_int, C.c_float]),
     "ya_sim_set_reduce_order": (C.c_int, [_sim, C.c_int]),
     "ya_slab_init": (C.c_int, [_sim, C.c_float, C.c_float, C.c_float, _pi]),
+    "ya_slab_info": (C.c_long, [_sim, C.c_int]),
     "ya_slab_n_own": (C.c_int, [_sim]),
     "ya_slab_n_local": (C.c_int, [_sim]),
     "ya_slab_setup": (C.c_int, [_sim, C.c_int, C.c_int, C.c_int, C.c_int]),
@@ -77,6 +78,9 @@ CORE_ABI = [
     "ya_append_rows", "ya_comm_unique_id", "ya_comm_create", "ya_comm_create_from_env",
     "ya_comm_destroy", "ya_comm_rank", "ya_comm_world", "ya_comm_exchange", "ya_comm_exchange_v",
     "ya_comm_allreduce_sum", "ya_comm_allreduce_host", "ya_comm_self_exchange",
+    "ya_grid_set_cube_range", "ya_copy_component", "ya_find_id", "ya_max_abs_diff", "ya_max_abs_diff_partials",
+    "ya_slab_guard_update", "ya_slab_pack", "ya_async_read_create", "ya_async_read_destroy",
+    "ya_async_read_begin", "ya_async_read_end",
 ]
 
 

@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "yalla_hip.h"
 
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(BLOCK) void k_bin(const float* __restrict__ X,
     int stride_f, int n, float cs, int gs, int n_cubes, const int* __restrict__ prev_pid,
     int n_prev, int* __restrict__ cube_of, int* __restrict__ rank, int* __restrict__ count,
     int* __restrict__ status, float* __restrict__ stash, int stash_f,
-    const int* __restrict__ d_n)
+    const int* __restrict__ d_n, int range_lo, int range_hi)
 {
     if (d_n) n = min(*d_n, n);  // the count still on its way to the host; n = launch bound
     int s = blockIdx.x * BLOCK + threadIdx.x;
@@ -89,6 +90,12 @@ __global__ __launch_bounds__(BLOCK) void k_bin(const float* __restrict__ X,
         if (id < 0 || id >= n_cubes) {
             atomicOr(status, YA_STATUS_OUT_OF_GRID);
             id = id < 0 ? 0 : n_cubes - 1;
+        }
+        // ya_grid_set_cube_range: the caller promised cube ids in [range_lo, range_hi) and the
+        // prefix sum only covers those; a cell outside is reported and kept inside (memory-safe)
+        if (id < range_lo || id >= range_hi) {
+            atomicOr(status, YA_STATUS_OUT_OF_RANGE);
+            id = id < range_lo ? range_lo : range_hi - 1;
         }
     }
     // Wave-aggregated counting: in visit order equal cube ids sit in adjacent
@@ -124,30 +131,34 @@ __device__ __forceinline__ int block_sum(int v, int* sh)
     return sh[0] + sh[1] + sh[2] + sh[3];
 }
 
+// (first_tile: the scan of a cube range, ya_grid_set_cube_range -- block b works on tile first_tile + b)
 __global__ __launch_bounds__(BLOCK) void k_tile_sum(
-    const int* __restrict__ count, int* __restrict__ tile_sums)
+    const int* __restrict__ count, int* __restrict__ tile_sums, int first_tile)
 {
     __shared__ int sh[4];
-    const int4* c4 = reinterpret_cast<const int4*>(count + (size_t)blockIdx.x * SCAN_TILE);
+    const int tile = first_tile + blockIdx.x;
+    const int4* c4 = reinterpret_cast<const int4*>(count + (size_t)tile * SCAN_TILE);
     int4 a = c4[threadIdx.x * 2], b = c4[threadIdx.x * 2 + 1];
     int v = a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
     int s = block_sum(v, sh);
-    if (threadIdx.x == 0) tile_sums[blockIdx.x] = s;
+    if (threadIdx.x == 0) tile_sums[tile] = s;
 }
 
 __global__ __launch_bounds__(BLOCK) void k_scan(int* __restrict__ count,
     const int* __restrict__ tile_sums, int n_cubes, int n, int* __restrict__ offs,
-    int* __restrict__ cube_start, int* __restrict__ cube_end, const int* __restrict__ d_n)
+    int* __restrict__ cube_start, int* __restrict__ cube_end, const int* __restrict__ d_n,
+    int first_tile, int all_tiles)
 {
     if (d_n) n = min(*d_n, n);
     __shared__ int sh[4];
     __shared__ int sh_wave[4];
-    // cells in all tiles before this one
+    // cells in all tiles before this one (a cube range: no cell lies below its first tile)
+    const int tile = first_tile + blockIdx.x;
     int before = 0;
-    for (int t = threadIdx.x; t < (int)blockIdx.x; t += BLOCK) before += tile_sums[t];
+    for (int t = first_tile + threadIdx.x; t < tile; t += BLOCK) before += tile_sums[t];
     before = block_sum(before, sh);
 
-    size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
+    size_t base = (size_t)tile * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
     int4* c4 = reinterpret_cast<int4*>(count + base);
     int4 a = c4[0], b = c4[1];
     int c[SCAN_ITEMS] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
@@ -186,8 +197,8 @@ __global__ __launch_bounds__(BLOCK) void k_scan(int* __restrict__ count,
     e4[1] = make_int4(e_[4], e_[5], e_[6], e_[7]);
     c4[0] = make_int4(0, 0, 0, 0);  // leave count[] zeroed for the next build
     c4[1] = make_int4(0, 0, 0, 0);
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == BLOCK - 1)
-        offs[(size_t)gridDim.x * SCAN_TILE] = n;
+    if (tile == all_tiles - 1 && threadIdx.x == BLOCK - 1)
+        offs[(size_t)all_tiles * SCAN_TILE] = n;
 }
 
 __global__ __launch_bounds__(BLOCK) void k_scatter(const int* __restrict__ cube_of,
@@ -465,6 +476,85 @@ __global__ __launch_bounds__(BLOCK) void k_append_rows(float* __restrict__ dst, 
     if (n_out && blockIdx.x == 0 && threadIdx.x == 0) *n_out = n_own + c_lo + c_hi;
 }
 
+
+// --- z-slab decomposition: drift guard, fixed point, a stage's all-reduce payload -------------
+__device__ __forceinline__ float block_max(float v, float* sh /* [4] */)
+{
+    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+}
+
+__global__ __launch_bounds__(BLOCK) void k_copy_component(const float* __restrict__ src, int stride_f,
+    int n, float* __restrict__ dst)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) dst[i] = src[(size_t)i * stride_f];
+}
+
+__global__ __launch_bounds__(BLOCK) void k_find_id(const int* __restrict__ ids, int n, int id, int* __restrict__ index)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n && ids[i] == id) *index = i;  // ids are unique
+}
+
+// partial[b] = max over block b's share of |a[i] - b[i]| (grid-stride; NaN differences count as +inf)
+__global__ __launch_bounds__(BLOCK) void k_max_abs_diff(const float* __restrict__ a, int a_stride_f,
+    const float* __restrict__ b, int b_stride_f, int n, float* __restrict__ partial)
+{
+    __shared__ float sh[4];
+    float m = 0.f;
+    for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * BLOCK) {
+        const float d = fabsf(a[(size_t)i * a_stride_f] - b[(size_t)i * b_stride_f]);
+        m = d == d ? fmaxf(m, d) : INFINITY;
+    }
+    m = block_max(m, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = m;
+}
+
+// The drift guard of a z-slab (include/slab_logic.inc), between a step's two stages: from the
+// per-block maxima of |z - z at selection| (own and mirrored cells, as the previous step left them)
+// and of this step's predictor |dz|.  state = {moved, predicted, request, error}: `error` if the
+// second stage is about to compute forces with a cell further than `limit` from where it was when
+// the mirrored cells were chosen (moved + predicted; the first stage saw `moved`, which is less),
+// `request` if the steps until a vote can act -- `lag_steps` of them at the present pace -- would
+// get there.
+__global__ __launch_bounds__(BLOCK) void k_slab_guard(const float* __restrict__ moved_partial, int n_moved,
+    const float* __restrict__ pred_partial, int n_pred, float limit, float lag_steps, float* __restrict__ state)
+{
+    __shared__ float sh[4];
+    float a = 0.f, p = 0.f;
+    for (int k = threadIdx.x; k < n_moved; k += BLOCK) a = fmaxf(a, moved_partial[k]);
+    for (int k = threadIdx.x; k < n_pred; k += BLOCK) p = fmaxf(p, pred_partial[k]);
+    a = block_max(a, sh);
+    p = block_max(p, sh);
+    if (threadIdx.x == 0) {
+        state[0] = a;
+        state[1] = p;
+        state[2] = !(a + lag_steps * p <= limit) ? 1.f : 0.f;
+        state[3] = !(a + p <= limit) ? 1.f : state[3];  // sticky until the next selection
+    }
+}
+
+// What k_reduce_final<NW, true> leaves behind the packed sum for a stage's all-reduce:
+// out[NW + 2] = this rank's vote for an early re-selection, out[NW + 3] = its error vote,
+// out[NW + 4 .. NW + 6] = x, y, z of row *fix_index of v if this rank owns the fixed point
+// (set_fixed(i), set_fixed_xy(i): every other rank adds zeros), out[NW + 7] = 0.
+template<int NW>
+__global__ void k_slab_pack_extra(const float* __restrict__ v, const float* __restrict__ guard_state,
+    int with_votes, int host_error, const int* __restrict__ fix_index, float* __restrict__ out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const bool votes = with_votes && guard_state;
+    out[NW + 2] = votes ? guard_state[2] : 0.f;
+    out[NW + 3] = (votes ? guard_state[3] : 0.f) + (host_error ? 1.f : 0.f);
+    const int f = fix_index ? *fix_index : -1;
+    for (int k = 0; k < 3; k++) out[NW + 4 + k] = f >= 0 ? v[(size_t)f * NW + k] : 0.f;
+    out[NW + 7] = 0.f;
+}
+
 template<int NW>
 int launch_reduce(const float* v, int n, float* out, float* ws, hipStream_t st, bool packed = false)
 {
@@ -476,6 +566,20 @@ int launch_reduce(const float* v, int n, float* out, float* ws, hipStream_t st, 
         k_reduce_final<NW, true><<<1, BLOCK, 0, st>>>(ws, B, n, out);
     else
         k_reduce_final<NW><<<1, BLOCK, 0, st>>>(ws, B, n, out);
+    return (int)hipGetLastError();
+}
+
+struct Pack_extra {
+    const float* guard_state;
+    int with_votes, host_error;
+    const int* fix_index;
+};
+template<int NW>
+int launch_pack(const float* v, int n, float* out, float* ws, hipStream_t st, const Pack_extra& x)
+{
+    const int rc = launch_reduce<NW>(v, n, out, ws, st, true);
+    if (rc) return rc;
+    k_slab_pack_extra<NW><<<1, 64, 0, st>>>(v, x.guard_state, x.with_votes, x.host_error, x.fix_index, out);
     return (int)hipGetLastError();
 }
 
@@ -494,6 +598,11 @@ struct ya_grid {
     int *d_prev_pid;  // private copy of the last build's point ids (visit order)
     int n_prev;       // cells in that build; 0 = none / unusable
     int* d_status;
+    // ya_grid_set_cube_range: the cubes that can hold cells, as whole scan tiles
+    // [range_first_tile, range_end_tile) = cube ids [range_lo, range_hi); range_n = the cell count
+    // of the last build that scanned EVERY tile since the range was set (-1: none yet): offs[] above
+    // the range holds that count, so only builds of the same count may scan the range alone
+    int range_first_tile, range_end_tile, range_lo, range_hi, range_n;
 };
 
 #define YA_TRY(expr)                      \
@@ -627,6 +736,11 @@ int ya_grid_create(int n_max, int grid_size, ya_grid** out)
     g->n_cubes = grid_size * grid_size * grid_size;
     g->n_tiles = ceil_div(g->n_cubes, SCAN_TILE);
     g->padded = (size_t)g->n_tiles * SCAN_TILE;
+    g->range_first_tile = -1;  // no cube range: every build scans every tile
+    g->range_end_tile = g->n_tiles;
+    g->range_lo = 0;
+    g->range_hi = g->n_cubes;
+    g->range_n = -1;
     const int rc = grid_allocate(g, n_max);
     if (rc) {  // nothing half-built is handed out or leaked
         ya_grid_destroy(g);
@@ -674,6 +788,19 @@ int ya_grid_offsets(ya_grid* g, const int** d_offs)
     return 0;
 }
 
+// The prefix sum over the cubes: every scan tile, or -- ya_grid_set_cube_range, and the count is the
+// one the last full scan saw -- the tiles of the range alone.
+static void launch_scan(ya_grid* g, int n, const int* d_n, hipStream_t st)
+{
+    const bool range_only = g->range_n >= 0 && g->range_n == n && !d_n;
+    const int first = range_only ? g->range_first_tile : 0;
+    const int tiles = range_only ? g->range_end_tile - g->range_first_tile : g->n_tiles;
+    k_tile_sum<<<tiles, BLOCK, 0, st>>>(g->d_count, g->d_tile_sums, first);
+    k_scan<<<tiles, BLOCK, 0, st>>>(g->d_count, g->d_tile_sums, g->n_cubes, n, g->d_offs, g->d_cube_start,
+        g->d_cube_end, d_n, first, g->n_tiles);
+    if (!range_only && g->range_first_tile >= 0) g->range_n = d_n ? -1 : n;
+}
+
 // First half of a build: binning, scan and scatter.  With d_n != nullptr the count is
 // read on the device (n_bound only sizes the launches), so these kernels can be queued
 // before the host knows n.
@@ -701,10 +828,8 @@ static int build_begin(ya_grid* g, const void* d_X, size_t stride_bytes, const i
     if (n_bound > 0)
         k_bin<<<nb_visit, BLOCK, 0, st>>>((const float*)d_X, stride_f, n_bound, cube_size,
             g->grid_size, g->n_cubes, g->d_prev_pid, n_prev, g->d_cube_of, g->d_rank, g->d_count,
-            g->d_status, stash, stride_f, d_n);
-    k_tile_sum<<<g->n_tiles, BLOCK, 0, st>>>(g->d_count, g->d_tile_sums);
-    k_scan<<<g->n_tiles, BLOCK, 0, st>>>(g->d_count, g->d_tile_sums, g->n_cubes, n_bound, g->d_offs,
-        g->d_cube_start, g->d_cube_end, d_n);
+            g->d_status, stash, stride_f, d_n, g->range_lo, g->range_hi);
+    launch_scan(g, n_bound, d_n, st);
     if (n_bound > 0)
         k_scatter<<<nb_visit, BLOCK, 0, st>>>(g->d_cube_of, g->d_rank, g->d_offs, n_bound,
             g->d_prev_pid, n_prev, g->d_arrival, g->d_cube_id, stash ? g->d_arrival_src : nullptr,
@@ -808,10 +933,8 @@ int ya_grid_rebuild_sorted(ya_grid* g, const void* d_prev_sorted, size_t entry_b
     if (n > 0)
         k_bin<<<nb, BLOCK, 0, st>>>((const float*)d_prev_sorted, entry_f, n, cube_size, g->grid_size,
             g->n_cubes, g->d_prev_pid, 0, g->d_cube_of, g->d_rank, g->d_count, g->d_status,
-            nullptr, 0, nullptr);
-    k_tile_sum<<<g->n_tiles, BLOCK, 0, st>>>(g->d_count, g->d_tile_sums);
-    k_scan<<<g->n_tiles, BLOCK, 0, st>>>(g->d_count, g->d_tile_sums, g->n_cubes, n, g->d_offs,
-        g->d_cube_start, g->d_cube_end, nullptr);
+            nullptr, 0, nullptr, g->range_lo, g->range_hi);
+    launch_scan(g, n, nullptr, st);
     if (n > 0) {
         const int id_word = (int)(point_bytes / 4);
         k_scatter<<<nb, BLOCK, 0, st>>>(g->d_cube_of, g->d_rank, g->d_offs, n, g->d_prev_pid, 0,
@@ -855,6 +978,31 @@ int ya_grid_build(ya_grid* g, const void* d_X, size_t stride_bytes, int n, float
 {
     return ya_grid_build_sorted(
         g, d_X, stride_bytes, nullptr, n, cube_size, nullptr, 0, nullptr, stream);
+}
+
+int ya_grid_set_cube_range(ya_grid* g, int cube_lo, int cube_hi)
+{
+    if (!g || cube_lo > cube_hi) return (int)hipErrorInvalidValue;
+    if (cube_lo <= 0 && cube_hi >= g->n_cubes) {  // the whole grid: as created
+        g->range_first_tile = -1;
+        g->range_end_tile = g->n_tiles;
+        g->range_lo = 0;
+        g->range_hi = g->n_cubes;
+        g->range_n = -1;
+        return 0;
+    }
+    // whole scan tiles, outwards
+    int first = (cube_lo < 0 ? 0 : cube_lo) / SCAN_TILE;
+    int end = ceil_div(cube_hi > g->n_cubes ? g->n_cubes : cube_hi, SCAN_TILE);
+    if (end > g->n_tiles) end = g->n_tiles;
+    if (first >= end) first = end > 0 ? end - 1 : 0;
+    if (first == g->range_first_tile && end == g->range_end_tile) return 0;  // unchanged: offs[] stay valid
+    g->range_first_tile = first;
+    g->range_end_tile = end;
+    g->range_lo = first * SCAN_TILE;
+    g->range_hi = end * SCAN_TILE < g->n_cubes ? end * SCAN_TILE : g->n_cubes;
+    g->range_n = -1;  // the next build scans every tile once
+    return 0;
 }
 
 int ya_grid_status(ya_grid* g, int* bits, int clear)
@@ -972,6 +1120,134 @@ int ya_reduce_mean(const void* d_v, int n_floats, int n, float* d_out, float* d_
 int ya_reduce_sum_packed(const void* d_v, int n_floats, int n, float* d_out, float* d_ws, void* stream)
 {
     return reduce_any(d_v, n_floats, n, d_out, d_ws, stream, true);
+}
+
+
+int ya_slab_pack(const void* d_v, int n_floats, int n, float* d_out, float* d_ws, const float* d_guard_state,
+    int with_votes, int host_error, const int* d_fix_index, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    const float* v = (const float*)d_v;
+    const Pack_extra x{d_guard_state, with_votes, host_error, d_fix_index};
+    switch (n_floats) {
+#define YA_PACK(NW) \
+    case NW:        \
+        return launch_pack<NW>(v, n, d_out, d_ws, st, x);
+        YA_PACK(3)
+        YA_PACK(4)
+        YA_PACK(5)
+        YA_PACK(6)
+        YA_PACK(7)
+        YA_PACK(8)
+        YA_PACK(9)
+        YA_PACK(10)
+        YA_PACK(11)
+        YA_PACK(12)
+        YA_PACK(13)
+        YA_PACK(14)
+        YA_PACK(15)
+        YA_PACK(16)
+#undef YA_PACK
+        default:
+            return (int)hipErrorInvalidValue;
+    }
+}
+
+int ya_copy_component(const void* d_src, size_t stride_bytes, int component, int n, float* d_dst, void* stream)
+{
+    if (!d_src || !d_dst || n < 0 || stride_bytes < 4 || stride_bytes % 4 || component < 0 ||
+        (size_t)component * 4 >= stride_bytes)
+        return (int)hipErrorInvalidValue;
+    if (n == 0) return 0;
+    k_copy_component<<<ceil_div(n, BLOCK), BLOCK, 0, (hipStream_t)stream>>>(
+        (const float*)d_src + component, (int)(stride_bytes / 4), n, d_dst);
+    return (int)hipGetLastError();
+}
+
+int ya_find_id(const int* d_ids, int n, int id, int* d_index, void* stream)
+{
+    if (!d_ids || !d_index || n < 0) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    YA_TRY(hipMemsetAsync(d_index, 0xff, sizeof(int), st));  // -1: not among these ids
+    if (n > 0) k_find_id<<<ceil_div(n, BLOCK), BLOCK, 0, st>>>(d_ids, n, id, d_index);
+    return (int)hipGetLastError();
+}
+
+int ya_max_abs_diff_partials(int n)
+{
+    int b = ceil_div(n > 0 ? n : 1, BLOCK);
+    return b > REDUCE_MAX_BLOCKS ? REDUCE_MAX_BLOCKS : b;
+}
+
+int ya_max_abs_diff(const float* d_a, size_t a_stride_bytes, const float* d_b, size_t b_stride_bytes, int n,
+    float* d_partial, void* stream)
+{
+    if (!d_a || !d_b || !d_partial || n < 0 || a_stride_bytes % 4 || b_stride_bytes % 4 || !a_stride_bytes ||
+        !b_stride_bytes)
+        return (int)hipErrorInvalidValue;
+    k_max_abs_diff<<<ya_max_abs_diff_partials(n), BLOCK, 0, (hipStream_t)stream>>>(
+        d_a, (int)(a_stride_bytes / 4), d_b, (int)(b_stride_bytes / 4), n, d_partial);
+    return (int)hipGetLastError();
+}
+
+int ya_slab_guard_update(const float* d_moved_partial, int n_moved, const float* d_pred_partial, int n_pred,
+    float limit, float lag_steps, float* d_state, void* stream)
+{
+    if (!d_state || n_moved < 0 || n_pred < 0 || (n_moved && !d_moved_partial) || (n_pred && !d_pred_partial))
+        return (int)hipErrorInvalidValue;
+    k_slab_guard<<<1, BLOCK, 0, (hipStream_t)stream>>>(
+        d_moved_partial, n_moved, d_pred_partial, n_pred, limit, lag_steps, d_state);
+    return (int)hipGetLastError();
+}
+
+// A few bytes read back without stalling the stream they are produced on: queued behind the
+// producer, collected later (ya_n_reader for any small record).
+struct ya_async_read {
+    void* h;  // pinned
+    size_t bytes;
+    hipEvent_t done;
+    int pending;
+};
+int ya_async_read_create(size_t bytes, ya_async_read** out)
+{
+    if (!out || bytes == 0 || bytes > 4096) return (int)hipErrorInvalidValue;
+    ya_async_read* r = (ya_async_read*)calloc(1, sizeof(ya_async_read));
+    if (!r) return (int)hipErrorOutOfMemory;
+    r->bytes = bytes;
+    hipError_t e = hipHostMalloc(&r->h, bytes, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&r->done, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        if (r->h) (void)hipHostFree(r->h);
+        free(r);
+        return (int)e;
+    }
+    *out = r;
+    return 0;
+}
+int ya_async_read_destroy(ya_async_read* r)
+{
+    if (!r) return 0;
+    (void)hipHostFree(r->h);
+    (void)hipEventDestroy(r->done);
+    free(r);
+    return 0;
+}
+int ya_async_read_begin(ya_async_read* r, const void* d_src, void* stream)
+{
+    if (!r || !d_src) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    YA_TRY(hipMemcpyAsync(r->h, d_src, r->bytes, hipMemcpyDeviceToHost, st));
+    YA_TRY(hipEventRecord(r->done, st));
+    r->pending = 1;
+    return 0;
+}
+int ya_async_read_end(ya_async_read* r, void* h_out)
+{
+    if (!r || !h_out || !r->pending) return (int)hipErrorInvalidValue;
+    YA_TRY(hipEventSynchronize(r->done));
+    memcpy(h_out, r->h, r->bytes);
+    r->pending = 0;
+    return 0;
 }
 
 }  // extern "C"

@@ -305,11 +305,68 @@ def slab_plan(X, world, cube_size=1.0, lib=None):
     return bounds, int(caps[0]), int(caps[1]), int(caps[2])
 
 
-def slab_bounds(z, world):
-    """The cut planes alone (numpy restatement of ya::slab_plan's quantiles, for tests)."""
-    z = np.sort(np.asarray(z, dtype=np.float32))
-    cuts = [z[(len(z) * r) // world] for r in range(1, world)]
-    return np.array([-np.inf] + cuts + [np.inf], dtype=np.float32)
+def slab_bounds(z, world, cube_size=1.0, margin=0.25, ghost_weight=0.6, snap_to_planes=True):
+    """The cut planes alone: numpy restatement of ya::slab_plan_sorted (include/slab_logic.inc) for
+    tests.  Cuts on the grid's cube-plane boundaries k * cube_size, chosen so that the largest
+    own + ghost_weight * mirrored cell count of a slab is smallest (greedy walk under a bisected
+    bound; interior slabs at least two planes thick); the z-quantiles of rounds 1-3 when the system
+    has too few planes for that."""
+    f32 = np.float32
+    z = np.sort(np.asarray(z, dtype=f32))
+    n = len(z)
+    cs, halo = f32(cube_size), f32(cube_size) * (f32(1.0) + f32(margin))
+
+    def below(v):
+        return int(np.searchsorted(z, f32(v), side="left"))
+
+    quantiles = np.array([-np.inf] + [z[(n * r) // world] for r in range(1, world)] + [np.inf], dtype=f32)
+    if not snap_to_planes or world <= 1 or n == 0:
+        return quantiles
+    k_lo, k_hi = int(np.floor(z[0] / cs)), int(np.floor(z[-1] / cs)) + 1
+    planes = k_hi - k_lo
+    if planes < 2 * world - 2 or planes > 4096:
+        return quantiles
+    at, under, over = [], [], []
+    for k in range(planes + 1):
+        f = f32(k_lo + k) * cs
+        at.append(n if k == planes else below(f))
+        under.append(at[k] - below(f - halo))
+        over.append(below(f + halo) - at[k])
+    at[0] = 0
+
+    def cost(a, b):
+        ghosts = (under[a] if a > 0 else 0) + (over[b] if b < planes else 0)
+        return float(at[b] - at[a]) + float(f32(ghost_weight)) * ghosts
+
+    def fits(T):
+        cuts = [0]
+        for r in range(world):
+            a = cuts[r]
+            if r + 1 == world:
+                cuts.append(planes)
+                return cuts if planes - a >= 1 and cost(a, planes) <= T else None
+            b_max = planes - 1 - 2 * (world - 2 - r)
+            b_min = a + (1 if r == 0 else 2)
+            b = b_max
+            while b >= b_min and cost(a, b) > T:
+                b -= 1
+            if b < b_min:
+                return None
+            cuts.append(b)
+        return cuts
+
+    lo, hi = 0.0, float(n) * (1.0 + 2.0 * float(f32(ghost_weight))) + 1.0
+    best = fits(hi)
+    if best is None:
+        return quantiles
+    for _ in range(60):
+        mid = 0.5 * (lo + hi)
+        cuts = fits(mid)
+        if cuts is not None:
+            hi, best = mid, cuts
+        else:
+            lo = mid
+    return np.array([-np.inf] + [f32(k_lo + best[r]) * cs for r in range(1, world)] + [np.inf], dtype=f32)
 
 
 class Slab:
@@ -356,9 +413,22 @@ class Slab:
     def step(self, dt, migrate=True):
         code = self._lib.ya_slab_step(self._h, float(dt), 1 if migrate else 0)
         if code != 0:
-            raise YallaError(f"rank {self.rank}: ya_slab_step failed ({code}): -4 = a ghost layer or the "
+            err = YallaError(f"rank {self.rank}: ya_slab_step failed ({code}): -4 = a ghost layer or the "
                              "migrating cells outgrew their message, -5 = n_max too small, -6 = a cell left "
-                             "through an outer face, -7 = no transport, -8 = the transport failed")
+                             "through an outer face, -7 = no transport, -8 = the transport failed, -11 = a cell "
+                             "of this rank drifted further than (halo - cube_size) / 2 between two selections of "
+                             "the mirrored cells, -12 = another rank failed")
+            err.code = code
+            raise err
+
+    def info(self):
+        """(selections of the mirrored cells so far, those the drift guard asked for, sticky failure code)"""
+        return tuple(int(self._lib.ya_slab_info(self._h, k)) for k in range(3))
+
+    def guard_state(self):
+        """The drift guard's (moved, predicted) of the last step: the largest |z - z at selection| the step
+        began with and the largest predictor |dz|, over this rank's own and mirrored cells."""
+        return tuple(self._lib.ya_slab_info(self._h, k) * 1e-6 for k in (3, 4))
 
     def own_cells(self):
         """(global ids, positions) of the cells this rank owns now."""
@@ -389,6 +459,10 @@ def run_slabs(slabs, dt, steps, migrate_every=1, device_memory=False):
                 s.step(dt, migrate=(k + 1) % migrate_every == 0 or k == steps - 1)
         except Exception as err:   # a failed rank must not leave the others at a barrier
             errors.append(err)
+            # (failures the ranks share through the all-reduce end every rank's step at the same point:
+            # give the others the moment they need to get there before the barrier is broken)
+            import time
+            time.sleep(0.5 if getattr(err, "code", 0) in (-4, -5, -6, -11, -12) else 0.0)
             shared.barrier.abort()
 
     threads = [threading.Thread(target=work, args=(s,)) for s in slabs]
@@ -397,4 +471,6 @@ def run_slabs(slabs, dt, steps, migrate_every=1, device_memory=False):
     for t in threads:
         t.join()
     if errors:
-        raise errors[0]
+        first = errors[0]
+        first.all_codes = [getattr(e, "code", None) for e in errors]
+        raise first
