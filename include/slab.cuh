@@ -81,6 +81,22 @@ struct Slab_device_ops {
             (const int*)lo, hi ? (const char*)hi + payload_offset : nullptr, (const int*)hi, cap, n_out,
             nullptr));
     }
+    static void pack_cells(void* const arrays[3], const size_t row_bytes[3], const int* idx, const int* count, int cap,
+        void* message, size_t header)
+    {
+        YA_CHECK(ya_pack_cells(arrays, row_bytes, idx, count, cap, message, header, nullptr));
+    }
+    static void append_cells(void* const arrays[3], const size_t row_bytes[3], int n_own, const void* lo, const void* hi,
+        int cap, size_t header, int* n_out, int* counts_out)
+    {
+        YA_CHECK(ya_append_cells(arrays, row_bytes, n_own, lo, hi, cap, header, n_out, counts_out, nullptr));
+    }
+    static void fill_holes(void* const arrays[3], const size_t row_bytes[3], const int* leave_lo, const int* count_lo,
+        const int* leave_hi, const int* count_hi, const int* movers, const int* count_movers, int n_new, int max_holes)
+    {
+        YA_CHECK(ya_fill_holes(arrays, row_bytes, leave_lo, count_lo, leave_hi, count_hi, movers, count_movers, n_new,
+            max_holes, nullptr));
+    }
     static void read_ints(const void* d, int k, int* out) { YA_CHECK(ya_memcpy_d2h(out, d, (size_t)k * sizeof(int))); }
     static void write_int(void* d, int v) { YA_CHECK(ya_memcpy_h2d(d, &v, sizeof(int))); }
     static void mean_from_total(const float* total, int n_floats, float* fix, int fix_mode)
@@ -90,9 +106,10 @@ struct Slab_device_ops {
     // drift guard and fixed point (include/yalla_hip.h)
     static void copy_z(const void* X, size_t stride, int n, float* z) { YA_CHECK(ya_copy_component(X, stride, 2, n, z, nullptr)); }
     static void find_id(const int* ids, int n, int id, int* index) { YA_CHECK(ya_find_id(ids, n, id, index, nullptr)); }
-    static int max_abs_diff(const float* a, size_t a_stride, const float* b, size_t b_stride, int n, float* partial)
+    static int max_abs_diff(const float* a, size_t a_stride, const float* b, size_t b_stride, int n, float lo_face,
+        float hi_face, float width, float* partial)
     {
-        YA_CHECK(ya_max_abs_diff(a, a_stride, b, b_stride, n, partial, nullptr));
+        YA_CHECK(ya_max_abs_diff(a, a_stride, b, b_stride, n, lo_face, hi_face, width, partial, nullptr));
         return ya_max_abs_diff_partials(n);
     }
     static void guard_update(const float* moved, int n_moved, const float* pred, int n_pred, float limit, float lag,
@@ -109,6 +126,9 @@ struct Slab_device_ops {
     }
     static void votes_destroy(void* r) { (void)ya_async_read_destroy((ya_async_read*)r); }
     static void votes_begin(void* r, const float* d_votes) { YA_CHECK(ya_async_read_begin((ya_async_read*)r, d_votes, nullptr)); }
+    // ... or stored by the corrector kernel itself at votes_target(); votes_mark: that kernel is in the stream
+    static float* votes_target(void* r) { return (float*)ya_async_read_target((ya_async_read*)r); }
+    static void votes_mark(void* r) { YA_CHECK(ya_async_read_mark((ya_async_read*)r, nullptr)); }
     static void votes_end(void* r, float* votes) { YA_CHECK(ya_async_read_end((ya_async_read*)r, votes)); }
 };
 }  // namespace ya

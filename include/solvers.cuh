@@ -238,9 +238,9 @@ __device__ __forceinline__ int xcd_eighth_tile(const int block, const int n_bloc
 #ifndef YA_XCD_RANGES
 #define YA_XCD_RANGES 2  /* contiguous ranges of tiles per XCD (1 = plain eighths) */
 #endif
+template<int RANGES = YA_XCD_RANGES>
 __device__ __forceinline__ int xcd_contiguous_tile(const int block, const int n_blocks)
 {
-    constexpr int RANGES = YA_XCD_RANGES;
     // parts of a multiple of 8 tiles each (block and block - k * part then sit on the same XCD);
     // the last part takes the remainder
     const int part = (n_blocks / RANGES) & ~7;
@@ -1123,7 +1123,8 @@ __global__ __launch_bounds__(bits::BLOCK, bits::Min_waves<Pt>::value) void grid_
     const int* __restrict__ cube_id, const int* __restrict__ offs, const int gs,
     const int n_cubes, const float cut2, Pt* __restrict__ d_dX, const bool has_gen,
     const int n_active, Pt* __restrict__ d_dX_sorted, const int* __restrict__ global_id,
-    const int part = 0, const int part_cube_lo = 0, const int part_cube_hi = 0)
+    const int part = 0, const int part_cube_lo = 0, const int part_cube_hi = 0, const int own_cube_lo = 0,
+    const int own_cube_hi = 0x7fffffff)
 {
     constexpr int FB = bits::BLOCK;
     constexpr int CAP = bits::Stage<Pt>::value;
@@ -1142,17 +1143,28 @@ __global__ __launch_bounds__(bits::BLOCK, bits::Min_waves<Pt>::value) void grid_
     // = the tiles in between, 0 = every tile.  Either launch spreads ITS tiles over all eight
     // XCDs (a launch that kept the whole array's mapping would occupy only the XCDs that own its
     // end of the array, and take as long as the full launch); blocks beyond its share exit.
+    // Round 4: cubes below own_cube_lo and from own_cube_hi up hold mirrored cells only (the caller
+    // knows how far own cells can have strayed): their tiles are not part of any launch.  And part 1
+    // is dealt to the XCDs in SIXTEEN short ranges each instead of two: its list of tiles runs
+    // mirrored cells -> own cells at the lower face and own -> mirrored at the upper one (a tile of
+    // mirrored cells costs nothing), and with two ranges the XCDs in the middle of the list got
+    // nearly twice the work of those at its ends -- all of them also carry an eighth of part 2.
     int tile;
     if (part == 0) {
         tile = xcd_contiguous_tile(blockIdx.x, gridDim.x);
     } else {
         const int tiles = gridDim.x;
-        const int t_lo = min((offs[min(part_cube_lo, n_cubes)] + FB - 1) / FB, tiles);
-        const int t_hi = max(min(offs[min(part_cube_hi, n_cubes)] / FB, tiles), t_lo);
-        const int mine = part == 1 ? t_lo + (tiles - t_hi) : t_hi - t_lo;
+        const int t_first = min(offs[min(max(own_cube_lo, 0), n_cubes)] / FB, tiles);
+        const int t_end = max(min((offs[min(own_cube_hi, n_cubes)] + FB - 1) / FB, tiles), t_first);
+        const int t_lo = max(min((offs[min(part_cube_lo, n_cubes)] + FB - 1) / FB, t_end), t_first);
+        const int t_hi = max(min(offs[min(part_cube_hi, n_cubes)] / FB, t_end), t_lo);
+        const int mine = part == 1 ? (t_lo - t_first) + (t_end - t_hi) : t_hi - t_lo;
         if ((int)blockIdx.x >= mine) return;
-        const int t = xcd_contiguous_tile(blockIdx.x, mine);
-        tile = part == 1 ? (t < t_lo ? t : t_hi + (t - t_lo)) : t_lo + t;
+        if (part == 1) {
+            const int t = xcd_contiguous_tile<16>(blockIdx.x, mine);
+            tile = t < t_lo - t_first ? t_first + t : t_hi + (t - (t_lo - t_first));
+        } else
+            tile = t_lo + xcd_contiguous_tile(blockIdx.x, mine);
     }
     const int s0 = tile * FB;
     const int s = s0 + threadIdx.x;
@@ -1742,6 +1754,18 @@ __device__ __forceinline__ float3 fix_from_total(const float* __restrict__ total
     const float* point = total + n_floats + 4;
     return float3{point[0], point[1], fix_mode == 1 ? point[2] : mean.z};
 }
+// The drift guard of a z-slab weighs a cell's movement by where it was when the mirrored cells were
+// chosen: fully within `width` = halo + limit of a face of the slab (those cells are mirrored, or
+// next in line), half elsewhere -- a cell further away has to cover `limit` more before it can
+// matter, so the guard's bound `limit` on the weighted maximum allows it 2 limit
+// (include/slab_logic.inc, guard_between_stages).
+struct Guard_band {
+    float lo_face = -INFINITY, hi_face = INFINITY, width = 0.f;
+    __host__ __device__ float weight(const float z) const
+    {
+        return fabsf(z - lo_face) <= width || fabsf(z - hi_face) <= width ? 1.f : 0.5f;
+    }
+};
 // partial[blockIdx.x] = the largest v of the workgroup (v >= 0, or NaN: counted as +inf); every
 // thread of an UPDATE_BLOCK-wide workgroup must call it.  For the drift guard of a z-slab.
 __device__ __forceinline__ void block_max_to(float v, float* __restrict__ partial)
@@ -1764,7 +1788,7 @@ template<typename Pt>
 __global__ __launch_bounds__(ya::UPDATE_BLOCK) void euler_step_sorted_mirrored(const int n, const float dt,
     const float* __restrict__ d_total, float* __restrict__ d_fix_out, const Pt* __restrict__ d_dX_sorted,
     const Pt* __restrict__ d_dX, ya::Entry<Pt>* __restrict__ d_sorted, const int n_active, const int fix_mode,
-    float* __restrict__ pred_partial)
+    float* __restrict__ pred_partial, const ya::Guard_band band)
 {
     const int s = blockIdx.x * ya::UPDATE_BLOCK + threadIdx.x;
     const float3 fix = ya::fix_from_total(d_total, sizeof(Pt) / sizeof(float), fix_mode);
@@ -1782,7 +1806,7 @@ __global__ __launch_bounds__(ya::UPDATE_BLOCK) void euler_step_sorted_mirrored(c
         dX.z -= fix.z;
         const float z0 = e.X.z;
         e.X = e.X + dX * dt;
-        moved = fabsf(e.X.z - z0);
+        moved = fabsf(e.X.z - z0) * band.weight(z0);
         d_sorted[s] = e;
     }
     if (pred_partial) ya::block_max_to(moved, pred_partial);
@@ -1827,14 +1851,21 @@ __global__ __launch_bounds__(ya::UPDATE_BLOCK) void heun_step_raw(const int n, c
 
 // heun_step_raw with the second stage's fixed velocity taken from the stage's all-reduced totals
 // (z-slab decomposition; see euler_step_sorted_mirrored).  z_selected / moved_partial (may be NULL):
-// per workgroup the largest |z - z when the mirrored cells were chosen| after this update.
+// per workgroup the largest |z - z when the mirrored cells were chosen| after this update, weighted
+// by the band.  votes_out (may be NULL; host memory the device can write): the all-reduced votes of
+// this stage, d_total1[n_floats + 2 .. + 3], for the host to collect when the next step begins.
 template<typename Pt>
 __global__ __launch_bounds__(ya::UPDATE_BLOCK) void heun_step_raw_total(const int n, const float dt,
     const Pt* __restrict__ d_dX, const float* __restrict__ d_fix, const Pt* __restrict__ d_dX1,
     const float* __restrict__ d_total1, Pt* __restrict__ d_X, float3* __restrict__ d_old_v, const int fix_mode,
-    const float* __restrict__ z_selected, float* __restrict__ moved_partial)
+    const float* __restrict__ z_selected, float* __restrict__ moved_partial, const ya::Guard_band band,
+    float* __restrict__ votes_out)
 {
     const int i = blockIdx.x * ya::UPDATE_BLOCK + threadIdx.x;
+    if (votes_out && i == 0) {
+        votes_out[0] = d_total1[sizeof(Pt) / sizeof(float) + 2];
+        votes_out[1] = d_total1[sizeof(Pt) / sizeof(float) + 3];
+    }
     float moved = 0.f;
     if (i < n) {
         const float3 fix1 = ya::fix_from_total(d_total1, sizeof(Pt) / sizeof(float), fix_mode);
@@ -1852,10 +1883,63 @@ __global__ __launch_bounds__(ya::UPDATE_BLOCK) void heun_step_raw_total(const in
         d_X[i] = X;
         d_old_v[i] = float3{
             (dX.x + dX1.x) * 0.5f, (dX.y + dX1.y) * 0.5f, (dX.z + dX1.z) * 0.5f};
-        if (z_selected) moved = fabsf(X.z - z_selected[i]);
+        if (z_selected) {
+            const float z0 = z_selected[i];
+            moved = fabsf(X.z - z0) * band.weight(z0);
+        }
     }
     if (moved_partial) ya::block_max_to(moved, moved_partial);
 }
+
+
+// ---- renumbering (opt-in, not in the reference) ---------------------------------------------------
+// Solution::renumber(properties ...) gives the cells new ids in cube order: the cell in slot s of
+// a fresh grid build becomes cell s.  The reference's contract is that ids never change -- models
+// index their own per-cell arrays by id (d_type[i], examples/passive_growth.cu:48-51) and append
+// daughters at d_X[n] -- so a model that has grown by division holds its cells in birth order,
+// spatially random, and every access of a pairwise functor to such an array (four per interacting
+// pair in passive_growth's relu_w_epithelium) is 64 different cache lines per wavefront
+// instruction: BASELINE configuration 4 moved 6.7 GB between L2 and the fabric per force launch
+// where 70 MB are needed, 78 % of its wave cycles waiting (profiles/r03_pmc_cfg4_*).  Only the
+// model knows all arrays that are indexed by cell id, so only the model can ask for a
+// renumbering, handing over every such array:
+//
+//     if (step % 10 == 0) cells.renumber(type, n_mes_nbs, n_epi_nbs);   // Property<...>&, Links&, or T* d_array
+//
+// Afterwards cell s is what cell order[s] was (d_X, d_old_v and the arrays handed over are
+// permuted alike, link endpoints are renamed), consecutive ids are neighbours in space, and so
+// are the daughters a proliferation kernel appends later in the order of their mothers.  Host
+// mirrors (h_X, h_prop) are stale until the next copy_to_host.  Results: every per-cell sum is
+// still accumulated cube by cube in ascending id, and the stable sort keeps the order of ids
+// inside a cube across the renumbering, so forces change only through cells that later move
+// between cubes (rounding of reordered sums); a model that draws random numbers by cell id draws
+// others.  The CPU oracle offers the same call (oracle/yalla_host.hpp) and both backends stay in
+// lock-step through it (tests/test_growth.py).
+namespace ya {
+template<typename T>
+__global__ __launch_bounds__(UPDATE_BLOCK) void permute_rows(const int n, const int* __restrict__ order,
+    const T* __restrict__ src, T* __restrict__ dst)
+{
+    const int s = blockIdx.x * UPDATE_BLOCK + threadIdx.x;
+    if (s < n) dst[s] = src[order[s]];
+}
+__global__ __launch_bounds__(UPDATE_BLOCK) void invert_order(const int n, const int* __restrict__ order,
+    int* __restrict__ new_id)
+{
+    const int s = blockIdx.x * UPDATE_BLOCK + threadIdx.x;
+    if (s < n) new_id[order[s]] = s;
+}
+// link endpoints (two ints per link: links.cuh Link{a, b}) renamed through new_id; ids >= n (none in a
+// consistent model) are left alone
+__global__ __launch_bounds__(UPDATE_BLOCK) void rename_ids(const int n_ids, const int* __restrict__ d_n_links,
+    const int n_cells, const int* __restrict__ new_id, int* __restrict__ ids)
+{
+    const int k = blockIdx.x * UPDATE_BLOCK + threadIdx.x;
+    if (k >= n_ids || k >= 2 * *d_n_links) return;
+    const int i = ids[k];
+    if (i >= 0 && i < n_cells) ids[k] = new_id[i];
+}
+}  // namespace ya
 
 
 // Solution<Pt, Solver> combines a method, Solver, with a point type, Pt: host
@@ -1979,6 +2063,7 @@ public:
         ya_free(d_fix);
         ya_free(d_fix_first);
         ya_free(d_workspace);
+        if (renumber_scratch) ya_free(renumber_scratch);
         drop_graph();
         if (capture_stream) (void)hipStreamDestroy(capture_stream);
     }
@@ -1995,6 +2080,27 @@ public:
         fix_com_z = true;
         fix_point = point_id;
     }
+    // Opt-in, not in the reference: new cell ids in cube order (see "renumbering" above).  Hand
+    // over EVERY array the model indexes by cell id: Property<T>& (anything with a d_prop member),
+    // Links& (anything with d_link / d_n: the endpoints are renamed), or a plain device pointer
+    // T* of >= n elements.  No-op for solvers without a grid (Tile_solver).
+    template<typename... Arrays>
+    void renumber(Arrays&... arrays)
+    {
+        const int n = get_d_n();
+        if (n <= 0) return;
+        const int* order = Computer<Pt>::cube_order(n, d_X);  // order[s] = the id of the cell in slot s
+        if (!order) return;
+        permute_array(order, n, d_X);
+        permute_array(order, n, d_old_v);
+        int* new_id = nullptr;
+        const int unused[] = {0, (renumber_one(order, n, arrays, new_id), 0)...};
+        (void)unused;
+        if (new_id) ya_free(new_id);
+        Computer<Pt>::ids_changed();
+        drop_graph();
+    }
+
     // Replaying the step as one hipGraph (Grid_solver without generic forces), opt-in:
     // 1 = whenever possible, -1 = for systems below YA_GRAPH_MAX_CELLS cells, 0 (default) =
     // never.  The graph is captured the second time the same step (functors, n, dt, fixed
@@ -2050,6 +2156,44 @@ protected:
         return n;
     }
     void check_status() { Computer<Pt>::check_status(); }
+    // renumber(): array[s] = array[order[s]] for s < n, through a scratch buffer that is kept
+    void* renumber_scratch = nullptr;
+    size_t renumber_scratch_bytes = 0;
+    template<typename T>
+    void permute_array(const int* order, const int n, T* d_array)
+    {
+        const size_t bytes = (size_t)n * sizeof(T);
+        if (renumber_scratch_bytes < bytes) {
+            if (renumber_scratch) ya_free(renumber_scratch);
+            renumber_scratch_bytes = 0;
+            YA_CHECK(ya_malloc(&renumber_scratch, (size_t)n_max * sizeof(T) > bytes ? (size_t)n_max * sizeof(T) : bytes));
+            renumber_scratch_bytes = (size_t)n_max * sizeof(T) > bytes ? (size_t)n_max * sizeof(T) : bytes;
+        }
+        ya::permute_rows<T><<<(n + ya::UPDATE_BLOCK - 1) / ya::UPDATE_BLOCK, ya::UPDATE_BLOCK>>>(
+            n, order, d_array, (T*)renumber_scratch);
+        YA_CHECK(ya_memcpy_d2d_async(d_array, renumber_scratch, bytes, nullptr));
+    }
+    template<typename T>
+    void renumber_one(const int* order, const int n, T*& d_array, int*&)
+    {
+        permute_array(order, n, d_array);
+    }
+    template<typename A>
+    auto renumber_one(const int* order, const int n, A& property, int*&) -> decltype((void)property.d_prop)
+    {
+        permute_array(order, n, property.d_prop);
+    }
+    template<typename L>
+    auto renumber_one(const int* order, const int n, L& links, int*& new_id) -> decltype((void)links.d_link)
+    {
+        if (!new_id) {
+            YA_CHECK(ya_malloc((void**)&new_id, (size_t)n * sizeof(int)));
+            ya::invert_order<<<(n + ya::UPDATE_BLOCK - 1) / ya::UPDATE_BLOCK, ya::UPDATE_BLOCK>>>(n, order, new_id);
+        }
+        const int n_ids = 2 * links.n_max;
+        ya::rename_ids<<<(n_ids + ya::UPDATE_BLOCK - 1) / ya::UPDATE_BLOCK, ya::UPDATE_BLOCK>>>(
+            n_ids, links.d_n, n, new_id, reinterpret_cast<int*>(links.d_link));
+    }
 
     // The velocity subtracted from dX.xyz for this stage, left in device memory.
     const float* fix_velocity(int n, Pt* d_rhs, bool mean, bool point_xy, bool first = false)
@@ -2130,28 +2274,40 @@ protected:
     // (d_total: the stage's all-reduced {sum, count pieces}; stage 1 leaves its fixed velocity in
     // d_fix_out, stage 2 reads it from there)
     // (fix_mode: ya::fix_from_total; pred_partial / z_selected + moved_partial: the drift guard's
-    // per-workgroup maxima, (n + UPDATE_BLOCK - 1) / UPDATE_BLOCK floats each, or NULL)
+    // per-workgroup maxima, (n + UPDATE_BLOCK - 1) / UPDATE_BLOCK floats each, or NULL; votes_out: see
+    // heun_step_raw_total)
     bool stage1_update_in_sorted_copy(int n, float dt, const float* d_total, float* d_fix_out, int n_active,
-        int fix_mode = 0, float* pred_partial = nullptr)
+        int fix_mode = 0, float* pred_partial = nullptr, const ya::Guard_band band = ya::Guard_band{})
     {
         if (sorted_stage_cells != n) return false;
-        Computer<Pt>::predictor_in_sorted_space_mirrored(n, dt, d_total, d_fix_out, n_active, d_dX, fix_mode, pred_partial);
+        Computer<Pt>::predictor_in_sorted_space_mirrored(n, dt, d_total, d_fix_out, n_active, d_dX, fix_mode, pred_partial, band);
         mirrored_in_sorted_copy = true;
         return true;
     }
     void stage2_update_raw(int n, float dt, const float* d_fix_stage1, const float* d_total_stage2, int fix_mode = 0,
-        const float* z_selected = nullptr, float* moved_partial = nullptr)
+        const float* z_selected = nullptr, float* moved_partial = nullptr, const ya::Guard_band band = ya::Guard_band{},
+        float* votes_out = nullptr)
     {
         heun_step_raw_total<<<(n + ya::UPDATE_BLOCK - 1) / ya::UPDATE_BLOCK, ya::UPDATE_BLOCK>>>(
-            n, dt, d_dX, d_fix_stage1, d_dX1, d_total_stage2, d_X, d_old_v, fix_mode, z_selected, moved_partial);
+            n, dt, d_dX, d_fix_stage1, d_dX1, d_total_stage2, d_X, d_old_v, fix_mode, z_selected, moved_partial, band, votes_out);
     }
     // what a rank puts into a stage's all-reduce (ya_slab_pack): the sum over its first n points and
-    // their count, its two votes, the fixed point's right-hand side if *d_fix_index is one of its cells
-    void stage_sum_packed(int stage, int n, float* d_out, const float* d_guard_state = nullptr, int with_votes = 0,
-        int host_error = 0, const int* d_fix_index = nullptr)
+    // their count, its two votes (the drift guard brought up to date in the same kernel if
+    // fold_guard), the fixed point's right-hand side if *d_fix_index is one of its cells
+    struct Guard_inputs {
+        const float* moved_partial = nullptr;
+        int n_moved = 0;
+        const float* pred_partial = nullptr;
+        int n_pred = 0;
+        float limit = 0.f, lag_steps = 0.f;
+        float* state = nullptr;
+    };
+    void stage_sum_packed(int stage, int n, float* d_out, const Guard_inputs& guard = Guard_inputs{}, int fold_guard = 0,
+        int with_votes = 0, int host_error = 0, const int* d_fix_index = nullptr)
     {
-        YA_CHECK(ya_slab_pack(stage == 1 ? d_dX : d_dX1, n_floats, n, d_out, d_workspace, d_guard_state, with_votes,
-            host_error, d_fix_index, nullptr));
+        YA_CHECK(ya_slab_pack(stage == 1 ? d_dX : d_dX1, n_floats, n, d_out, d_workspace, guard.moved_partial, guard.n_moved,
+            guard.pred_partial, guard.n_pred, guard.limit, guard.lag_steps, guard.state, fold_guard, with_votes, host_error,
+            d_fix_index, nullptr));
     }
 
     // Sorted-space pipeline (Grid_solver without generic forces): the predictor lives in
@@ -2282,8 +2438,10 @@ protected:
     void check_status() {}
     void begin_build(const Pt*, const int*, int) {}
     void cancel_build() {}
+    const int* cube_order(int, const Pt*) { return nullptr; }  // no grid: renumber() is a no-op
+    void ids_changed() {}
     void predictor_in_sorted_space(int, float, const float*, int) {}
-    void predictor_in_sorted_space_mirrored(int, float, const float*, float*, int, const Pt*, int, float*) {}
+    void predictor_in_sorted_space_mirrored(int, float, const float*, float*, int, const Pt*, int, float*, ya::Guard_band) {}
     void ghosts_in_sorted_space(int, int, const Pt*) {}
     template<Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction>
     void pwints_from_sorted(int, Pt*, int, bool) {}
@@ -2381,6 +2539,9 @@ public:
             d_prev_v, n, cube_size, d_sorted, d_sorted_v, stream));
     }
     const int* offsets() const { return d_offs; }
+    // The ids the last build saw mean other cells now (Solution::renumber): the next build visits
+    // the cells in storage order instead of the last build's.
+    void forget_order() { YA_CHECK(ya_grid_forget_order(handle)); }
     // A promise that every cell's cube id lies in [cube_lo, cube_hi): builds then scan those cubes
     // only (ya_grid_set_cube_range; a z-slab holds cells in a fraction of the grid's planes).
     void set_cube_range(const int cube_lo, const int cube_hi) { YA_CHECK(ya_grid_set_cube_range(handle, cube_lo, cube_hi)); }
@@ -2467,6 +2628,9 @@ public:
     // other than grid_force_bits compute everything in the first call.
     int force_part = 0;
     int force_part_cube_lo = 0, force_part_cube_hi = 0x7fffffff;
+    // ... and the cubes that can hold own cells at all: [force_own_cube_lo, force_own_cube_hi); tiles of
+    // cubes outside hold mirrored cells only and are left out of both launches
+    int force_own_cube_lo = 0, force_own_cube_hi = 0x7fffffff;
     // z-slab decomposition: local cell index -> global id (own cells, then ghosts); pairwise
     // functors are then called with global (i, j).  NULL (default): local = global.
     const int* d_global_id = nullptr;
@@ -2589,7 +2753,7 @@ protected:
         (n + ya::bits::BLOCK - 1) / ya::bits::BLOCK, ya::bits::BLOCK, n, d_cells, d_cells_v,   \
         (const int*)grid.d_cube_id, grid.offsets(), grid.grid_size, grid.n_cubes, cut2, d_dX,  \
         has_gen, n_active, d_dX_in_cell_order, (const int*)d_global_id, part, force_part_cube_lo, \
-        force_part_cube_hi)
+        force_part_cube_hi, force_own_cube_lo, force_own_cube_hi)
             const bool stage_v = n <= stage_v_max;
             if (d_global_id) {
                 if (stage_v) {
@@ -2615,6 +2779,14 @@ protected:
 #undef YA_COOP_LAUNCH
 #undef YA_FORCE_LAUNCH
     }
+    // Heun_solver::renumber: the cells' ids in (cube, id) order = the point ids of a fresh build
+    const int* cube_order(const int n, const Pt* d_X)
+    {
+        grid.build(n, d_X, cube_size);
+        return grid.d_point_id;
+    }
+    // ... after which cell s IS slot s: the next build visits the cells in storage order
+    void ids_changed() { grid.forget_order(); }
     // The part of the first stage's grid build that can be queued before the host knows
     // n (Heun_solver::take_step); pwints then only finishes the build.
     void begin_build(const Pt* d_X, const int* d_n, const int n_bound)
@@ -2645,10 +2817,10 @@ protected:
             n, dt, d_fix, d_dX_sorted, d_sorted, n_active);
     }
     void predictor_in_sorted_space_mirrored(const int n, const float dt, const float* d_total, float* d_fix_out,
-        const int n_active, const Pt* d_dX, const int fix_mode, float* pred_partial)
+        const int n_active, const Pt* d_dX, const int fix_mode, float* pred_partial, const ya::Guard_band band)
     {
         euler_step_sorted_mirrored<<<(n + ya::UPDATE_BLOCK - 1) / ya::UPDATE_BLOCK, ya::UPDATE_BLOCK, 0, stream>>>(
-            n, dt, d_total, d_fix_out, d_dX_sorted, d_dX, d_sorted, n_active, fix_mode, pred_partial);
+            n, dt, d_total, d_fix_out, d_dX_sorted, d_dX, d_sorted, n_active, fix_mode, pred_partial, band);
     }
     void ghosts_in_sorted_space(const int n, const int n_active, const Pt* d_X1)
     {

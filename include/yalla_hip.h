@@ -137,6 +137,12 @@ int ya_grid_rebuild_sorted(ya_grid* g, const void* d_prev_sorted, size_t entry_b
     size_t point_bytes, const void* d_prev_sorted_v, int n, float cube_size, void* d_sorted_out,
     void* d_sorted_v_out, void* stream);
 
+/* A build visits the cells in the previous build's sorted order (they move little between builds:
+ * neighbouring lanes then bin into neighbouring counters).  After the caller has given the cells
+ * new ids (Solution::renumber, include/solvers.cuh) that order means other cells: the next build
+ * visits them in storage order.  Performance only; results never depend on the visit order. */
+int ya_grid_forget_order(ya_grid* g);
+
 /* A promise about where cells can be: every cell's cube id lies in [cube_lo, cube_hi).  Builds
  * then run their prefix sum (k_tile_sum, k_scan: 16 bytes written per cube of the grid, whatever
  * it holds) over the scan tiles of that range only -- once one build with the same cell count has
@@ -208,16 +214,38 @@ int ya_append_rows(void* d_dst, size_t row_bytes, int n_own, const void* d_src_l
 
 /* ---- z-slab decomposition: drift guard, fixed point, a stage's all-reduce payload ---------- */
 
+/* A cell's record in a slab is three arrays with their own row widths -- X (the point), old_v (12 bytes),
+ * the global id (4) --; these move all three in ONE launch (a row width of 0 skips an array).
+ * ya_pack_cells: a message = header_bytes (>= 16; the first int = *d_count as it is, so that a
+ * receiver sees an overflow), then `cap` rows of array 0, of array 1, of array 2; rows k <
+ * min(*d_count, cap) are d_src[f][d_idx[k]].
+ * ya_append_cells: the rows of up to two such messages (NULL = none) go behind the n_own rows of
+ * d_dst[f]: min(count, cap) of the lower one, then of the upper one; *d_n_out = the new total,
+ * d_counts_out[0 .. 1] = the counts as sent (either may be NULL).
+ * ya_fill_holes: cells whose indices are in the ascending lists d_leave_lo / d_leave_hi have left;
+ * the first n_new rows are made whole again by moving the staying cells of the tail [n_new, ...) --
+ * d_movers[k] + n_new, ascending, *d_count_movers of them -- into the holes below n_new (lower list's
+ * holes first).  max_holes sizes the launch.  Every other cell keeps its row. */
+int ya_pack_cells(const void* const d_src[3], const size_t row_bytes[3], const int* d_idx, const int* d_count, int cap,
+    void* d_message, size_t header_bytes, void* stream);
+int ya_append_cells(void* const d_dst[3], const size_t row_bytes[3], int n_own, const void* d_message_lo,
+    const void* d_message_hi, int cap, size_t header_bytes, int* d_n_out, int* d_counts_out, void* stream);
+int ya_fill_holes(void* const d_arrays[3], const size_t row_bytes[3], const int* d_leave_lo, const int* d_count_lo,
+    const int* d_leave_hi, const int* d_count_hi, const int* d_movers, const int* d_count_movers, int n_new,
+    int max_holes, void* stream);
+
 /* d_dst[i] = float number `component` of row i of d_src (rows of stride_bytes): a slab keeps the z
  * of its own and mirrored cells at the moment the mirrored cells were chosen. */
 int ya_copy_component(const void* d_src, size_t stride_bytes, int component, int n, float* d_dst, void* stream);
 /* *d_index = the position of `id` in d_ids[0 .. n) (unique ids), or -1: which local cell is the
  * fixed point of set_fixed(i) / set_fixed_xy(i) (solvers.cuh:197-208), if this rank owns it. */
 int ya_find_id(const int* d_ids, int n, int id, int* d_index, void* stream);
-/* d_partial[b] = max over block b's share of |d_a[i] - d_b[i]|, i < n (element strides in bytes; a NaN
- * counts as +inf); ya_max_abs_diff_partials(n) <= 1024 partials are written. */
+/* d_partial[b] = max over block b's share of w_i |d_a[i] - d_b[i]|, i < n (element strides in bytes; a NaN
+ * counts as +inf), with w_i = 1 where d_b[i] lies within `width` of lo_face or hi_face (either may be
+ * infinite) and 1/2 elsewhere: the drift guard weighs a cell by how near a face of its slab it was
+ * (include/solvers.cuh, ya::Guard_band).  ya_max_abs_diff_partials(n) <= 1024 partials are written. */
 int ya_max_abs_diff(const float* d_a, size_t a_stride_bytes, const float* d_b, size_t b_stride_bytes, int n,
-    float* d_partial, void* stream);
+    float lo_face, float hi_face, float width, float* d_partial, void* stream);
 int ya_max_abs_diff_partials(int n);
 /* The drift guard between a step's two stages.  d_state = {moved, predicted, request, error}: moved =
  * max of the n_moved partials (|z - z at selection| as the previous step left the cells), predicted =
@@ -231,9 +259,11 @@ int ya_slab_guard_update(const float* d_moved_partial, int n_moved, const float*
  * vote for an early re-selection and [n_floats + 3] = its error vote (d_guard_state[2], [3] if
  * with_votes, plus 1 if host_error), [n_floats + 4 .. + 6] = x, y, z of row *d_fix_index of d_v (the
  * fixed point's right-hand side, solvers.cuh:250-253,269-272) or zeros if that index is negative or
- * the pointer NULL, [n_floats + 7] = 0.  d_out: n_floats + 8 floats. */
-int ya_slab_pack(const void* d_v, int n_floats, int n, float* d_out, float* d_ws, const float* d_guard_state,
-    int with_votes, int host_error, const int* d_fix_index, void* stream);
+ * the pointer NULL, [n_floats + 7] = 0.  With fold_guard the drift guard is brought up to date first,
+ * in the same kernel (ya_slab_guard_update's arguments).  d_out: n_floats + 8 floats. */
+int ya_slab_pack(const void* d_v, int n_floats, int n, float* d_out, float* d_ws, const float* d_moved_partial,
+    int n_moved, const float* d_pred_partial, int n_pred, float limit, float lag_steps, float* d_guard_state,
+    int fold_guard, int with_votes, int host_error, const int* d_fix_index, void* stream);
 
 /* `bytes` (<= 4096) read back without stalling the stream that produces them: _begin queues the copy
  * into pinned memory behind everything already in `stream`, _end waits for it (ya_n_reader for any
@@ -242,6 +272,10 @@ typedef struct ya_async_read ya_async_read;
 int ya_async_read_create(size_t bytes, ya_async_read** out);
 int ya_async_read_destroy(ya_async_read* r);
 int ya_async_read_begin(ya_async_read* r, const void* d_src, void* stream);
+/* ... or written by a kernel itself: _target is the (device-visible) address the kernel stores the
+ * record at, _mark notes that everything queued in `stream` so far includes that kernel. */
+void* ya_async_read_target(ya_async_read* r);
+int ya_async_read_mark(ya_async_read* r, void* stream);
 int ya_async_read_end(ya_async_read* r, void* h_out);
 
 /* ---- Slab neighbours over RCCL (multi-GPU, one process per GPU) ------------- */

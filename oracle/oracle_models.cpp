@@ -67,6 +67,53 @@ struct Oracle_slab_ops {
     }
     if (n_out) *n_out = n;
 }
+// a cell's record -- three arrays with their own row widths -- moved together (ya_pack_cells,
+// ya_append_cells, ya_fill_holes of include/yalla_hip.h, restated serially)
+    static void pack_cells(void* const arrays[3], const size_t row_bytes[3], const int* idx, const int* count, int cap,
+    void* message, size_t header)
+{
+    int* head = (int*)message;
+    head[0] = *count;
+    head[1] = head[2] = head[3] = 0;
+    const int m = *count < 0 ? 0 : (*count < cap ? *count : cap);
+    char* out = (char*)message + header;
+    for (int f = 0; f < 3; f++) {
+        for (int k = 0; k < m; k++)
+            memcpy(out + (size_t)k * row_bytes[f], (const char*)arrays[f] + (size_t)idx[k] * row_bytes[f], row_bytes[f]);
+        out += (size_t)cap * row_bytes[f];
+    }
+}
+    static void append_cells(void* const arrays[3], const size_t row_bytes[3], int n_own, const void* lo, const void* hi,
+    int cap, size_t header, int* n_out, int* counts_out)
+{
+    const void* messages[2] = {lo, hi};
+    int n = n_own;
+    for (int d = 0; d < 2; d++) {
+        const int sent = messages[d] ? *(const int*)messages[d] : 0;
+        if (counts_out) counts_out[d] = sent;
+        const int c = sent < 0 ? 0 : (sent > cap ? cap : sent);
+        size_t offset = header;
+        for (int f = 0; f < 3; f++) {
+            if (c > 0)
+                memcpy((char*)arrays[f] + (size_t)n * row_bytes[f], (const char*)messages[d] + offset, (size_t)c * row_bytes[f]);
+            offset += (size_t)cap * row_bytes[f];
+        }
+        n += c;
+    }
+    if (n_out) *n_out = n;
+}
+    static void fill_holes(void* const arrays[3], const size_t row_bytes[3], const int* leave_lo, const int* count_lo,
+    const int* leave_hi, const int* count_hi, const int* movers, const int* count_movers, int n_new, int)
+{
+    int k = 0;
+    const int* lists[2] = {leave_lo, leave_hi};
+    const int* counts[2] = {count_lo, count_hi};
+    for (int d = 0; d < 2; d++)
+        for (int j = 0; lists[d] && j < *counts[d] && lists[d][j] < n_new && k < *count_movers; j++, k++)
+            for (int f = 0; f < 3; f++)
+                memcpy((char*)arrays[f] + (size_t)lists[d][j] * row_bytes[f],
+                    (const char*)arrays[f] + (size_t)(n_new + movers[k]) * row_bytes[f], row_bytes[f]);
+}
     static void read_ints(const void* d, int k, int* out) { memcpy(out, d, (size_t)k * sizeof(int)); }
     static void write_int(void* d, int v) { *(int*)d = v; }
 // The cell count travels through the float all-reduce as two exact pieces (low 12 bits and
@@ -105,12 +152,16 @@ struct Oracle_slab_ops {
     for (int i = 0; i < n; i++)
         if (ids[i] == id) *index = i;
 }
-    static int max_abs_diff(const float* a, size_t a_stride, const float* b, size_t b_stride, int n, float* partial)
+// the drift guard's weighted maximum (ya_max_abs_diff): full weight for cells that were within `width`
+// of a face of the slab, half elsewhere
+    static int max_abs_diff(const float* a, size_t a_stride, const float* b, size_t b_stride, int n, float lo_face,
+    float hi_face, float width, float* partial)
 {
     float m = 0.f;
     for (int i = 0; i < n; i++) {
-        const float d = fabsf(*(const float*)((const char*)a + (size_t)i * a_stride) -
-                              *(const float*)((const char*)b + (size_t)i * b_stride));
+        const float z = *(const float*)((const char*)b + (size_t)i * b_stride);
+        const float w = fabsf(z - lo_face) <= width || fabsf(z - hi_face) <= width ? 1.f : 0.5f;
+        const float d = fabsf(*(const float*)((const char*)a + (size_t)i * a_stride) - z) * w;
         m = d == d ? fmaxf(m, d) : INFINITY;
     }
     partial[0] = m;
@@ -132,6 +183,8 @@ struct Oracle_slab_ops {
     static void votes_destroy(void* r) { free(r); }
     static void votes_begin(void* r, const float* votes) { memcpy(r, votes, 2 * sizeof(float)); }
     static void votes_end(void* r, float* votes) { memcpy(votes, r, 2 * sizeof(float)); }
+    static float* votes_target(void* r) { return (float*)r; }
+    static void votes_mark(void*) {}
     static void pack_sum(const float* sum, int n_floats, int n_own, float* out)
 {
     for (int k = 0; k < n_floats; k++) out[k] = sum[k];

@@ -301,6 +301,7 @@ public:
     Tile_computer(int n_max) {}
 
 protected:
+    const int* cube_order(int, const Pt*) { return nullptr; }  // no grid: renumber() is a no-op
     template<Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction>
     void pwints(const int n, const Pt* d_X, const float3* d_old_v, Pt* d_dX,
         float3* d_sum_v, float* d_sum_friction, int n_active = -1)
@@ -439,6 +440,12 @@ public:
 
 protected:
     int nhood[27];
+    // Heun_solver::renumber (not in the reference): the cells' ids in (cube, id) order
+    const int* cube_order(int n, const Pt* d_X)
+    {
+        grid.build(n, d_X, cube_size);
+        return grid.d_point_id;
+    }
     template<Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction>
     void pwints(int n, const Pt* d_X, const float3* d_old_v, Pt* d_dX,
         float3* d_sum_v, float* d_sum_friction, int n_active = -1)
@@ -516,7 +523,50 @@ public:
     }
     Ya_reduce_order reduce_order = YA_REDUCE_SERIAL;
 
+    // Not in the reference: the HIP engine's opt-in Solution::renumber (include/solvers.cuh,
+    // "renumbering"), restated.  Cell s becomes what cell order[s] was, order = the point ids of a
+    // fresh grid build (cube by cube, ascending id inside a cube); d_X, d_old_v and every array
+    // handed over (Property: d_prop; Links: endpoints renamed; plain pointers) follow.
+    template<typename... Arrays>
+    void renumber(Arrays&... arrays)
+    {
+        const int n = get_d_n();
+        if (n <= 0) return;
+        const int* order = Computer<Pt>::cube_order(n, d_X);
+        if (!order) return;
+        const std::vector<int> fixed(order, order + n);  // (the grid's array is rebuilt by the next step)
+        permute_array(fixed, d_X);
+        permute_array(fixed, d_old_v);
+        const int unused[] = {0, (renumber_one(fixed, arrays), 0)...};
+        (void)unused;
+    }
+
 protected:
+    template<typename T>
+    static void permute_array(const std::vector<int>& order, T* array)
+    {
+        std::vector<T> tmp(order.size());
+        for (size_t s = 0; s < order.size(); s++) tmp[s] = array[order[s]];
+        for (size_t s = 0; s < order.size(); s++) array[s] = tmp[s];
+    }
+    template<typename T>
+    static void renumber_one(const std::vector<int>& order, T*& array) { permute_array(order, array); }
+    template<typename A>
+    static auto renumber_one(const std::vector<int>& order, A& property) -> decltype((void)property.d_prop)
+    {
+        permute_array(order, property.d_prop);
+    }
+    template<typename L>
+    static auto renumber_one(const std::vector<int>& order, L& links) -> decltype((void)links.d_link)
+    {
+        const int n = (int)order.size();
+        std::vector<int> new_id(n);
+        for (int s = 0; s < n; s++) new_id[order[s]] = s;
+        for (int k = 0; k < *links.d_n && k < links.n_max; k++) {
+            if (links.d_link[k].a >= 0 && links.d_link[k].a < n) links.d_link[k].a = new_id[links.d_link[k].a];
+            if (links.d_link[k].b >= 0 && links.d_link[k].b < n) links.d_link[k].b = new_id[links.d_link[k].b];
+        }
+    }
     Pt *d_X, *d_dX, *d_X1, *d_dX1;
     float3 *d_old_v, *d_sum_v;
     float* d_sum_friction;

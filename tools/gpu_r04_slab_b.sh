@@ -1,0 +1,23 @@
+#!/bin/bash
+# Round 4, second look: slab tests, then the 10 M-cell / 8-slab rehearsal after the hole-filling
+# migration, the fused cell records, the drift guard folded into the reduction and the sixteen-range
+# mapping of the boundary launch; planes against quantile cuts once more; wall clock and device time.
+out=$GRAFT_REPO_ROOT/gpurun_out/r04_slab_b; mkdir -p $out
+cd $GRAFT_REPO_ROOT
+timeout 1500 python -m pytest tests/test_slab.py tests/test_core_abi_gpu.py -x -q -m gpu > $out/pytest.txt 2>&1; echo "pytest rc=$?"; tail -5 $out/pytest.txt
+for plan in planes quantile; do
+  if [ $plan = quantile ]; then export YALLA_SLAB_PLAN=quantile; fi
+  timeout 900 tools/slab_rehearsal 10000000 8 24 3 8 > $out/rehearsal_10M_w8_$plan.json 2> $out/rehearsal_10M_w8_$plan.err; echo "$plan rc=$?"
+done
+unset YALLA_SLAB_PLAN
+cd /tmp && export TMPDIR=/tmp
+export YALLA_REHEARSAL_MARKERS=1
+for plan in planes quantile; do
+  if [ $plan = quantile ]; then export YALLA_SLAB_PLAN=quantile; fi
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/slab8_$plan -o k -- $GRAFT_REPO_ROOT/tools/slab_rehearsal 10000000 8 24 3 8 > $out/slab8_traced_$plan.json 2> $out/slab8_$plan.err
+  SLAB_TIMELINE_RANK=4 python3 $GRAFT_REPO_ROOT/tools/slab_trace_summary.py $out/slab8_$plan/k_kernel_trace.csv 27 > $out/slab8_device_time_$plan.json 2> $out/timeline_rank4_$plan.txt
+  cp $out/slab8_$plan/k_kernel_stats.csv $out/slab8_kernel_stats_$plan.csv
+  rm -rf $out/slab8_$plan
+done
+unset YALLA_SLAB_PLAN YALLA_REHEARSAL_MARKERS
+ls -la $out

@@ -500,14 +500,18 @@ __global__ __launch_bounds__(BLOCK) void k_find_id(const int* __restrict__ ids, 
     if (i < n && ids[i] == id) *index = i;  // ids are unique
 }
 
-// partial[b] = max over block b's share of |a[i] - b[i]| (grid-stride; NaN differences count as +inf)
+// partial[b] = max over block b's share of w_i |a[i] - b[i]|, w_i = 1 if b[i] lies within `width` of
+// lo_face or hi_face, else 1/2 (grid-stride; NaN differences count as +inf)
 __global__ __launch_bounds__(BLOCK) void k_max_abs_diff(const float* __restrict__ a, int a_stride_f,
-    const float* __restrict__ b, int b_stride_f, int n, float* __restrict__ partial)
+    const float* __restrict__ b, int b_stride_f, int n, float lo_face, float hi_face, float width,
+    float* __restrict__ partial)
 {
     __shared__ float sh[4];
     float m = 0.f;
     for (long i = (long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (long)gridDim.x * BLOCK) {
-        const float d = fabsf(a[(size_t)i * a_stride_f] - b[(size_t)i * b_stride_f]);
+        const float z = b[(size_t)i * b_stride_f];
+        const float w = fabsf(z - lo_face) <= width || fabsf(z - hi_face) <= width ? 1.f : 0.5f;
+        const float d = fabsf(a[(size_t)i * a_stride_f] - z) * w;
         m = d == d ? fmaxf(m, d) : INFINITY;
     }
     m = block_max(m, sh);
@@ -520,39 +524,163 @@ __global__ __launch_bounds__(BLOCK) void k_max_abs_diff(const float* __restrict_
 // second stage is about to compute forces with a cell further than `limit` from where it was when
 // the mirrored cells were chosen (moved + predicted; the first stage saw `moved`, which is less),
 // `request` if the steps until a vote can act -- `lag_steps` of them at the present pace -- would
-// get there.
-__global__ __launch_bounds__(BLOCK) void k_slab_guard(const float* __restrict__ moved_partial, int n_moved,
-    const float* __restrict__ pred_partial, int n_pred, float limit, float lag_steps, float* __restrict__ state)
+// get there.  Folded into the last kernel of the second stage's reduction (k_slab_pack_final), which
+// puts the votes into the all-reduce's payload; ya_slab_guard_update runs it by itself.
+struct Guard_args {
+    const float* moved_partial;
+    int n_moved;
+    const float* pred_partial;
+    int n_pred;
+    float limit, lag_steps;
+    float* state;  // NULL: no guard
+};
+__device__ __forceinline__ void guard_fold(const Guard_args& g, float* sh /* [4] */)
 {
-    __shared__ float sh[4];
     float a = 0.f, p = 0.f;
-    for (int k = threadIdx.x; k < n_moved; k += BLOCK) a = fmaxf(a, moved_partial[k]);
-    for (int k = threadIdx.x; k < n_pred; k += BLOCK) p = fmaxf(p, pred_partial[k]);
+    for (int k = threadIdx.x; k < g.n_moved; k += BLOCK) a = fmaxf(a, g.moved_partial[k]);
+    for (int k = threadIdx.x; k < g.n_pred; k += BLOCK) p = fmaxf(p, g.pred_partial[k]);
     a = block_max(a, sh);
     p = block_max(p, sh);
     if (threadIdx.x == 0) {
-        state[0] = a;
-        state[1] = p;
-        state[2] = !(a + lag_steps * p <= limit) ? 1.f : 0.f;
-        state[3] = !(a + p <= limit) ? 1.f : state[3];  // sticky until the next selection
+        g.state[0] = a;
+        g.state[1] = p;
+        g.state[2] = !(a + g.lag_steps * p <= g.limit) ? 1.f : 0.f;
+        g.state[3] = !(a + p <= g.limit) ? 1.f : g.state[3];  // sticky until the next selection
+    }
+    __syncthreads();
+}
+__global__ __launch_bounds__(BLOCK) void k_slab_guard(const Guard_args g)
+{
+    __shared__ float sh[4];
+    guard_fold(g, sh);
+}
+
+// The last kernel of a rank's contribution to a stage's all-reduce (ya_slab_pack): k_reduce_final's
+// packed sum {sum[NW], n & 4095, n >> 12}, then out[NW + 2] = this rank's vote for an early
+// re-selection, out[NW + 3] = its error vote (the drift guard's, folded here first if `fold_guard`,
+// plus 1 if host_error), out[NW + 4 .. NW + 6] = x, y, z of row *fix_index of v if this rank owns the
+// fixed point (set_fixed(i), set_fixed_xy(i): every other rank adds zeros), out[NW + 7] = 0.
+template<int NW>
+__global__ __launch_bounds__(BLOCK) void k_slab_pack_final(const float* __restrict__ partials, int n_partials, int n,
+    const float* __restrict__ v, const Guard_args guard, int fold_guard, int with_votes, int host_error,
+    const int* __restrict__ fix_index, float* __restrict__ out)
+{
+    __shared__ float sh[NW * BLOCK];
+    float acc[NW];
+#pragma unroll
+    for (int k = 0; k < NW; k++) acc[k] = 0.f;
+    for (int p = threadIdx.x; p < n_partials; p += BLOCK) {
+#pragma unroll
+        for (int k = 0; k < NW; k++) acc[k] = acc[k] + partials[(size_t)p * NW + k];
+    }
+    fold256<NW>(acc, sh);
+    if (threadIdx.x < NW) out[threadIdx.x] = sh[threadIdx.x * BLOCK];
+    __syncthreads();
+    if (fold_guard && guard.state) guard_fold(guard, sh);
+    if (threadIdx.x == 0) {
+        out[NW] = (float)(n & 4095);
+        out[NW + 1] = (float)(n >> 12);
+        const bool votes = with_votes && guard.state;
+        out[NW + 2] = votes ? guard.state[2] : 0.f;
+        out[NW + 3] = (votes ? guard.state[3] : 0.f) + (host_error ? 1.f : 0.f);
+        const int f = fix_index ? *fix_index : -1;
+        for (int k = 0; k < 3; k++) out[NW + 4 + k] = f >= 0 ? v[(size_t)f * NW + k] : 0.f;
+        out[NW + 7] = 0.f;
     }
 }
 
-// What k_reduce_final<NW, true> leaves behind the packed sum for a stage's all-reduce:
-// out[NW + 2] = this rank's vote for an early re-selection, out[NW + 3] = its error vote,
-// out[NW + 4 .. NW + 6] = x, y, z of row *fix_index of v if this rank owns the fixed point
-// (set_fixed(i), set_fixed_xy(i): every other rank adds zeros), out[NW + 7] = 0.
-template<int NW>
-__global__ void k_slab_pack_extra(const float* __restrict__ v, const float* __restrict__ guard_state,
-    int with_votes, int host_error, const int* __restrict__ fix_index, float* __restrict__ out)
+
+// --- z-slab decomposition: a cell's fields {X, old_v, global id} moved together ------------------
+// Up to three arrays with their own row widths (in floats) handled by ONE launch: a message is
+// packed, two messages are appended, holes are filled.  One thread per float of a cell's record.
+struct Fields3 {
+    const float* src[3];
+    float* dst[3];
+    int row_f[3];
+};
+__device__ __forceinline__ void locate(const Fields3& f, long e, int total_f, int* cell, int* field, int* off)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const bool votes = with_votes && guard_state;
-    out[NW + 2] = votes ? guard_state[2] : 0.f;
-    out[NW + 3] = (votes ? guard_state[3] : 0.f) + (host_error ? 1.f : 0.f);
-    const int f = fix_index ? *fix_index : -1;
-    for (int k = 0; k < 3; k++) out[NW + 4 + k] = f >= 0 ? v[(size_t)f * NW + k] : 0.f;
-    out[NW + 7] = 0.f;
+    *cell = (int)(e / total_f);
+    int r = (int)(e % total_f);
+    int fl = 0;
+    while (fl < 2 && r >= f.row_f[fl]) r -= f.row_f[fl++];
+    *field = fl;
+    *off = r;
+}
+// dst[f][k] = src[f][idx[k]] for k < min(*count, cap); header[0] = *count as it is (a receiver sees
+// an overflow), header[1 .. 3] = 0
+__global__ __launch_bounds__(BLOCK) void k_pack_cells(const Fields3 f, const int* __restrict__ idx,
+    const int* __restrict__ count, int cap, int* __restrict__ header)
+{
+    const int total_f = f.row_f[0] + f.row_f[1] + f.row_f[2];
+    const int m = min(max(*count, 0), cap);
+    if (header && blockIdx.x == 0 && threadIdx.x < 4) header[threadIdx.x] = threadIdx.x == 0 ? *count : 0;
+    for (long e = (long)blockIdx.x * BLOCK + threadIdx.x; e < (long)m * total_f; e += (long)gridDim.x * BLOCK) {
+        int k, fl, off;
+        locate(f, e, total_f, &k, &fl, &off);
+        f.dst[fl][(size_t)k * f.row_f[fl] + off] = f.src[fl][(size_t)idx[k] * f.row_f[fl] + off];
+    }
+}
+// rows [n_own, n_own + c_lo) of every field from the lower message, then c_hi rows from the upper one
+// (counts = the messages' first ints, clamped to [0, cap]; a missing message counts as empty);
+// *n_out = n_own + c_lo + c_hi, counts_out[0 .. 1] = the counts AS SENT
+struct Append3 {
+    const float* lo[3];
+    const float* hi[3];
+    float* dst[3];
+    int row_f[3];
+};
+__global__ __launch_bounds__(BLOCK) void k_append_cells(const Append3 a, int n_own, const int* __restrict__ count_lo,
+    const int* __restrict__ count_hi, int cap, int* __restrict__ n_out, int* __restrict__ counts_out)
+{
+    const int sent_lo = count_lo ? *count_lo : 0, sent_hi = count_hi ? *count_hi : 0;
+    const int c_lo = min(max(sent_lo, 0), cap), c_hi = min(max(sent_hi, 0), cap);
+    const int total_f = a.row_f[0] + a.row_f[1] + a.row_f[2];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (n_out) *n_out = n_own + c_lo + c_hi;
+        if (counts_out) {
+            counts_out[0] = sent_lo;
+            counts_out[1] = sent_hi;
+        }
+    }
+    Fields3 f;
+    for (int k = 0; k < 3; k++) f.row_f[k] = a.row_f[k];
+    for (long e = (long)blockIdx.x * BLOCK + threadIdx.x; e < (long)(c_lo + c_hi) * total_f; e += (long)gridDim.x * BLOCK) {
+        int k, fl, off;
+        locate(f, e, total_f, &k, &fl, &off);
+        const float* src = k < c_lo ? a.lo[fl] + (size_t)k * a.row_f[fl] : a.hi[fl] + (size_t)(k - c_lo) * a.row_f[fl];
+        a.dst[fl][(size_t)(n_own + k) * a.row_f[fl] + off] = src[off];
+    }
+}
+// Cells that left a slab leave holes in its arrays; the holes below n_new are filled with the cells
+// that stay but sit at or above n_new (as many: both are what is missing from / surplus to the first
+// n_new rows).  Holes = the entries < n_new of the two ascending lists of leavers (lower face first),
+// movers[k] + n_new = the k-th staying cell of the tail, ascending.  Every other cell keeps its row:
+// the grid's memory of the last order stays good, and nothing but the few movers is copied.
+__device__ __forceinline__ int first_not_below(const int* __restrict__ list, int n, int bound)
+{
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (list[mid] < bound) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+__global__ __launch_bounds__(BLOCK) void k_fill_holes(const Fields3 f, const int* __restrict__ leave_lo,
+    const int* __restrict__ count_lo, const int* __restrict__ leave_hi, const int* __restrict__ count_hi,
+    const int* __restrict__ movers, const int* __restrict__ count_movers, int n_new)
+{
+    const int a = leave_lo ? first_not_below(leave_lo, *count_lo, n_new) : 0;
+    const int b = leave_hi ? first_not_below(leave_hi, *count_hi, n_new) : 0;
+    const int holes = min(a + b, *count_movers);
+    const int total_f = f.row_f[0] + f.row_f[1] + f.row_f[2];
+    for (long e = (long)blockIdx.x * BLOCK + threadIdx.x; e < (long)holes * total_f; e += (long)gridDim.x * BLOCK) {
+        int k, fl, off;
+        locate(f, e, total_f, &k, &fl, &off);
+        const int hole = k < a ? leave_lo[k] : leave_hi[k - a];
+        const int mover = n_new + movers[k];
+        f.dst[fl][(size_t)hole * f.row_f[fl] + off] = f.src[fl][(size_t)mover * f.row_f[fl] + off];
+    }
 }
 
 template<int NW>
@@ -570,16 +698,18 @@ int launch_reduce(const float* v, int n, float* out, float* ws, hipStream_t st, 
 }
 
 struct Pack_extra {
-    const float* guard_state;
-    int with_votes, host_error;
+    Guard_args guard;
+    int fold_guard, with_votes, host_error;
     const int* fix_index;
 };
 template<int NW>
 int launch_pack(const float* v, int n, float* out, float* ws, hipStream_t st, const Pack_extra& x)
 {
-    const int rc = launch_reduce<NW>(v, n, out, ws, st, true);
-    if (rc) return rc;
-    k_slab_pack_extra<NW><<<1, 64, 0, st>>>(v, x.guard_state, x.with_votes, x.host_error, x.fix_index, out);
+    int B = ceil_div(n, BLOCK);
+    if (B < 1) B = 1;
+    if (B > REDUCE_MAX_BLOCKS) B = REDUCE_MAX_BLOCKS;
+    k_reduce_partial<NW><<<B, BLOCK, 0, st>>>(v, n, ws);
+    k_slab_pack_final<NW><<<1, BLOCK, 0, st>>>(ws, B, n, v, x.guard, x.fold_guard, x.with_votes, x.host_error, x.fix_index, out);
     return (int)hipGetLastError();
 }
 
@@ -980,6 +1110,13 @@ int ya_grid_build(ya_grid* g, const void* d_X, size_t stride_bytes, int n, float
         g, d_X, stride_bytes, nullptr, n, cube_size, nullptr, 0, nullptr, stream);
 }
 
+int ya_grid_forget_order(ya_grid* g)
+{
+    if (!g) return (int)hipErrorInvalidValue;
+    g->n_prev = 0;  // visit = identity (k_bin, visit())
+    return 0;
+}
+
 int ya_grid_set_cube_range(ya_grid* g, int cube_lo, int cube_hi)
 {
     if (!g || cube_lo > cube_hi) return (int)hipErrorInvalidValue;
@@ -1123,12 +1260,16 @@ int ya_reduce_sum_packed(const void* d_v, int n_floats, int n, float* d_out, flo
 }
 
 
-int ya_slab_pack(const void* d_v, int n_floats, int n, float* d_out, float* d_ws, const float* d_guard_state,
-    int with_votes, int host_error, const int* d_fix_index, void* stream)
+int ya_slab_pack(const void* d_v, int n_floats, int n, float* d_out, float* d_ws, const float* d_moved_partial,
+    int n_moved, const float* d_pred_partial, int n_pred, float limit, float lag_steps, float* d_guard_state,
+    int fold_guard, int with_votes, int host_error, const int* d_fix_index, void* stream)
 {
     hipStream_t st = (hipStream_t)stream;
     const float* v = (const float*)d_v;
-    const Pack_extra x{d_guard_state, with_votes, host_error, d_fix_index};
+    if (fold_guard && d_guard_state && ((n_moved && !d_moved_partial) || (n_pred && !d_pred_partial) || n_moved < 0 || n_pred < 0))
+        return (int)hipErrorInvalidValue;
+    const Pack_extra x{Guard_args{d_moved_partial, n_moved, d_pred_partial, n_pred, limit, lag_steps, d_guard_state},
+        fold_guard, with_votes, host_error, d_fix_index};
     switch (n_floats) {
 #define YA_PACK(NW) \
     case NW:        \
@@ -1151,6 +1292,83 @@ int ya_slab_pack(const void* d_v, int n_floats, int n, float* d_out, float* d_ws
         default:
             return (int)hipErrorInvalidValue;
     }
+}
+
+static bool fields_ok(const size_t row_bytes[3])
+{
+    for (int k = 0; k < 3; k++)
+        if (row_bytes[k] % 4) return false;
+    return row_bytes[0] + row_bytes[1] + row_bytes[2] > 0;
+}
+static int blocks_for(long floats)
+{
+    long b = (floats + BLOCK - 1) / BLOCK;
+    return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+int ya_pack_cells(const void* const d_src[3], const size_t row_bytes[3], const int* d_idx, const int* d_count, int cap,
+    void* d_message, size_t header_bytes, void* stream)
+{
+    if (!d_src || !row_bytes || !d_idx || !d_count || !d_message || cap < 0 || header_bytes < 16 || header_bytes % 4 ||
+        !fields_ok(row_bytes))
+        return (int)hipErrorInvalidValue;
+    Fields3 f;
+    char* out = (char*)d_message + header_bytes;
+    int total_f = 0;
+    for (int k = 0; k < 3; k++) {
+        f.src[k] = (const float*)d_src[k];
+        f.dst[k] = (float*)out;
+        f.row_f[k] = (int)(row_bytes[k] / 4);
+        if (f.row_f[k] && !d_src[k]) return (int)hipErrorInvalidValue;
+        out += (size_t)cap * row_bytes[k];
+        total_f += f.row_f[k];
+    }
+    k_pack_cells<<<blocks_for((long)cap * total_f), BLOCK, 0, (hipStream_t)stream>>>(f, d_idx, d_count, cap, (int*)d_message);
+    return (int)hipGetLastError();
+}
+
+int ya_append_cells(void* const d_dst[3], const size_t row_bytes[3], int n_own, const void* d_message_lo,
+    const void* d_message_hi, int cap, size_t header_bytes, int* d_n_out, int* d_counts_out, void* stream)
+{
+    if (!d_dst || !row_bytes || n_own < 0 || cap < 0 || header_bytes < 16 || !fields_ok(row_bytes))
+        return (int)hipErrorInvalidValue;
+    Append3 a;
+    size_t offset = header_bytes;
+    int total_f = 0;
+    for (int k = 0; k < 3; k++) {
+        a.dst[k] = (float*)d_dst[k];
+        a.row_f[k] = (int)(row_bytes[k] / 4);
+        if (a.row_f[k] && !d_dst[k]) return (int)hipErrorInvalidValue;
+        a.lo[k] = d_message_lo ? (const float*)((const char*)d_message_lo + offset) : nullptr;
+        a.hi[k] = d_message_hi ? (const float*)((const char*)d_message_hi + offset) : nullptr;
+        offset += (size_t)cap * row_bytes[k];
+        total_f += a.row_f[k];
+    }
+    k_append_cells<<<blocks_for(2L * cap * total_f), BLOCK, 0, (hipStream_t)stream>>>(
+        a, n_own, (const int*)d_message_lo, (const int*)d_message_hi, cap, d_n_out, d_counts_out);
+    return (int)hipGetLastError();
+}
+
+int ya_fill_holes(void* const d_arrays[3], const size_t row_bytes[3], const int* d_leave_lo, const int* d_count_lo,
+    const int* d_leave_hi, const int* d_count_hi, const int* d_movers, const int* d_count_movers, int n_new,
+    int max_holes, void* stream)
+{
+    if (!d_arrays || !row_bytes || !d_movers || !d_count_movers || n_new < 0 || max_holes < 0 || !fields_ok(row_bytes) ||
+        (d_leave_lo && !d_count_lo) || (d_leave_hi && !d_count_hi))
+        return (int)hipErrorInvalidValue;
+    if (max_holes == 0) return 0;
+    Fields3 f;
+    int total_f = 0;
+    for (int k = 0; k < 3; k++) {
+        f.src[k] = (const float*)d_arrays[k];
+        f.dst[k] = (float*)d_arrays[k];
+        f.row_f[k] = (int)(row_bytes[k] / 4);
+        if (f.row_f[k] && !d_arrays[k]) return (int)hipErrorInvalidValue;
+        total_f += f.row_f[k];
+    }
+    k_fill_holes<<<blocks_for((long)max_holes * total_f), BLOCK, 0, (hipStream_t)stream>>>(
+        f, d_leave_lo, d_count_lo, d_leave_hi, d_count_hi, d_movers, d_count_movers, n_new);
+    return (int)hipGetLastError();
 }
 
 int ya_copy_component(const void* d_src, size_t stride_bytes, int component, int n, float* d_dst, void* stream)
@@ -1180,13 +1398,13 @@ int ya_max_abs_diff_partials(int n)
 }
 
 int ya_max_abs_diff(const float* d_a, size_t a_stride_bytes, const float* d_b, size_t b_stride_bytes, int n,
-    float* d_partial, void* stream)
+    float lo_face, float hi_face, float width, float* d_partial, void* stream)
 {
     if (!d_a || !d_b || !d_partial || n < 0 || a_stride_bytes % 4 || b_stride_bytes % 4 || !a_stride_bytes ||
         !b_stride_bytes)
         return (int)hipErrorInvalidValue;
     k_max_abs_diff<<<ya_max_abs_diff_partials(n), BLOCK, 0, (hipStream_t)stream>>>(
-        d_a, (int)(a_stride_bytes / 4), d_b, (int)(b_stride_bytes / 4), n, d_partial);
+        d_a, (int)(a_stride_bytes / 4), d_b, (int)(b_stride_bytes / 4), n, lo_face, hi_face, width, d_partial);
     return (int)hipGetLastError();
 }
 
@@ -1196,7 +1414,7 @@ int ya_slab_guard_update(const float* d_moved_partial, int n_moved, const float*
     if (!d_state || n_moved < 0 || n_pred < 0 || (n_moved && !d_moved_partial) || (n_pred && !d_pred_partial))
         return (int)hipErrorInvalidValue;
     k_slab_guard<<<1, BLOCK, 0, (hipStream_t)stream>>>(
-        d_moved_partial, n_moved, d_pred_partial, n_pred, limit, lag_steps, d_state);
+        Guard_args{d_moved_partial, n_moved, d_pred_partial, n_pred, limit, lag_steps, d_state});
     return (int)hipGetLastError();
 }
 
@@ -1238,6 +1456,16 @@ int ya_async_read_begin(ya_async_read* r, const void* d_src, void* stream)
     hipStream_t st = (hipStream_t)stream;
     YA_TRY(hipMemcpyAsync(r->h, d_src, r->bytes, hipMemcpyDeviceToHost, st));
     YA_TRY(hipEventRecord(r->done, st));
+    r->pending = 1;
+    return 0;
+}
+// The same record written by a kernel itself (the pinned buffer is device-visible at its own address):
+// _target is where the kernel stores it, _mark notes "whatever is in `stream` now has written it".
+void* ya_async_read_target(ya_async_read* r) { return r ? r->h : nullptr; }
+int ya_async_read_mark(ya_async_read* r, void* stream)
+{
+    if (!r) return (int)hipErrorInvalidValue;
+    YA_TRY(hipEventRecord(r->done, (hipStream_t)stream));
     r->pending = 1;
     return 0;
 }
