@@ -165,6 +165,10 @@ def parse(argv=None):
                          "(protrusion-like load for Links::link_forces)")
     ap.add_argument("--tile-lanes", type=int, default=1,
                     help="Tile_solver models: Tile_computer::lanes_per_cell (1 = reference semantics, 16 = tile_force_coop)")
+    ap.add_argument("--renumber-every", type=int, default=0,
+                    help="configs 3 / 4: the model calls Solution::renumber(type, mes_nbs, epi_nbs) -- new cell ids in "
+                         "cube order, opt-in, not in the reference -- once before the warm-up and after every this-many-th "
+                         "step (0 = never: ids stay in birth order as in the reference)")
     ap.add_argument("--graph", type=int, default=0,
                     help="Heun_solver::graph_steps: 1 = replay the step as a hipGraph, -1 = below 400 k "
                          "cells only, 0 = plain launches (default)")
@@ -188,7 +192,7 @@ def kernel_source_sha():
 
 
 def counters_key(args, n_total):
-    """Key of this workload in profiles/r03_counters.json (None: no counters kept for it)."""
+    """Key of this workload in profiles/r04_counters.json (None: no counters kept for it)."""
     if args.slab or args.gpus > 1 or args.force_variant not in (-1, 2):
         return None
     tier = "" if args.arith == "exact" else "_fast"
@@ -196,20 +200,21 @@ def counters_key(args, n_total):
         return ("springs_1M" if n_total == 1_000_000 else "springs_10M") + tier
     if args.model == "sorting_grid" and n_total == 10_000:
         return "cfg2_sorting_10k" + tier
+    renumbered = "_renumbered" if args.renumber_every > 0 else ""
     if args.model == "branching_grid":
-        return "cfg3_branching_100k" + tier
+        return "cfg3_branching_100k" + renumbered + tier
     if args.model == "passive_growth_grid":
-        return "cfg4_passive_growth_1M" + tier
+        return "cfg4_passive_growth_1M" + renumbered + tier
     return None
 
 
 def measured_counters(kernel_key):
     """Per-launch PMC figures of the dominant kernel from the committed rocprofv3 passes of
-    this same command (profiles/r03_counters.json, written by tools/roofline_json.py):
+    this same command (profiles/r04_counters.json, written by tools/roofline_json.py):
     HBM-side traffic (FETCH_SIZE and WRITE_SIZE from separate --pmc passes, KiB, FETCH_SIZE
     doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950) and the
     ceilings that bind this kernel.  Returns ({}, None) when there is no record."""
-    path = os.path.join(ROOT, "profiles", "r03_counters.json")
+    path = os.path.join(ROOT, "profiles", "r04_counters.json")
     try:
         with open(path) as f:
             rec = json.load(f)[kernel_key]
@@ -222,7 +227,7 @@ def measured_counters(kernel_key):
     head = {"commit": rec.get("head"), "kernel_sha": rec.get("kernel_sha")}
     if rec.get("kernel_sha") != kernel_source_sha():
         # measured on an older kernel: do not pass the numbers off as this build's
-        sys.stderr.write("bench.py: profiles/r03_counters.json[%s] was measured on another kernel source "
+        sys.stderr.write("bench.py: profiles/r04_counters.json[%s] was measured on another kernel source "
                          "(%s != %s); traffic and PMC fractions omitted\n" % (kernel_key, rec.get("kernel_sha"), kernel_source_sha()))
         return {"stale_counters": True}, head
     return out, head
@@ -252,7 +257,7 @@ def grid_size_for(n, dist):
     return max(gs, 8)
 
 
-def cpu_baseline(model, n, gs, dist, dt, steps, state=None):
+def cpu_baseline(model, n, gs, dist, dt, steps, state=None, renumber_every=0):
     """The oracle (oracle/, a plain C++ port of the reference's algorithm, one
     thread) timed on the same workload: `steps` take_steps of the same system."""
     from yalla_amd import _ffi, cases
@@ -265,6 +270,9 @@ def cpu_baseline(model, n, gs, dist, dt, steps, state=None):
             s.random_sphere(dist, 42)
         if model.startswith("sorting"):
             s.set_param("n_cells", n)
+        if renumber_every > 0:
+            s.set_param("renumber_now", 1)
+            s.set_param("renumber_every", renumber_every)
         t0 = time.perf_counter()
         s.take_step(dt, steps)
         elapsed = time.perf_counter() - t0
@@ -443,6 +451,12 @@ def main(argv=None):
                 sim.set_param("graph", args.graph)
         if args.model.startswith("sorting"):
             sim.set_param("n_cells", n_total)
+        if args.renumber_every > 0:
+            if args.model not in STATE_MODELS:
+                sys.exit("bench.py: --renumber-every is for the models that index per-cell arrays by id "
+                         "(passive_growth_grid, branching_grid)")
+            sim.set_param("renumber_now", 1)
+            sim.set_param("renumber_every", args.renumber_every)
         if args.model.endswith("_tile") and args.tile_lanes != 1:
             sim.set_param("tile_lanes", args.tile_lanes)
         n_links = 0
@@ -591,6 +605,7 @@ def main(argv=None):
                 "force_variant": args.force_variant,
                 "arith": args.arith,
                 "links": n_links if not slab_path else 0,
+                "renumber_every": args.renumber_every,
                 "parallelism": "1 GPU" if world == 1 else
                                f"{world} z-slabs of one {n_total}-cell system, step sequenced in C++ (ya_slab_step: "
                                "mirrored ghost cells, one message of right-hand sides per neighbour and stage beside the "
@@ -644,7 +659,8 @@ def main(argv=None):
         if counters.get("stale_counters"):
             out["roofline"]["stale_counters"] = True
         if world == 1 and not args.slab and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.model, n_total, gs, args.dist, dt, args.cpu_steps, state)
+            out["cpu_baseline"] = cpu_baseline(args.model, n_total, gs, args.dist, dt, args.cpu_steps, state,
+                                               args.renumber_every)
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)

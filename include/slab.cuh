@@ -112,8 +112,7 @@ struct Slab_device_ops {
         YA_CHECK(ya_max_abs_diff(a, a_stride, b, b_stride, n, lo_face, hi_face, width, partial, nullptr));
         return ya_max_abs_diff_partials(n);
     }
-    static void guard_update(const float* moved, int n_moved, const float* pred, int n_pred, float limit, float lag,
-        float* state)
+    static void guard_update(float* moved, int n_moved, float* pred, int n_pred, float limit, float lag, float* state)
     {
         YA_CHECK(ya_slab_guard_update(moved, n_moved, pred, n_pred, limit, lag, state, nullptr));
     }

@@ -968,16 +968,27 @@ namespace bits {
 // made the launch SLOWER, 1431 -> 1615 us -- that kernel is bound by the address path of the
 // functor's own global accesses (d_type[i], d_type[j], d_mes_nbs[i] += 1 by original id: 64 cache
 // lines per wavefront instruction, TA 73 % busy), and more wavefronts only queue there.
+// Round 4: once the MODEL keeps its ids in cube order (Solution::renumber) those accesses are
+// neighbouring lines and the picture turns round -- four wavefronts per SIMD and one hit per trip
+// are then the faster build, 652 -> 585 us per launch (profiles/r04_cfg4_renumber_ab.txt).  The
+// solver launches that build (LOCAL_IDS) for wide points after a renumbering and the reference-
+// semantics build otherwise; both are the same kernel source.
 #ifndef YA_BITS_MIN_WAVES_WIDE
 #define YA_BITS_MIN_WAVES_WIDE 1
 #endif
-template<typename Pt>
+#ifndef YA_BITS_MIN_WAVES_WIDE_LOCAL
+#define YA_BITS_MIN_WAVES_WIDE_LOCAL 4
+#endif
+#ifndef YA_BITS_POPS_WIDE_LOCAL
+#define YA_BITS_POPS_WIDE_LOCAL 1
+#endif
+template<typename Pt, bool LOCAL_IDS = false>
 struct Min_waves {
-    static constexpr int value = sizeof(Pt) <= 16 ? 1 : YA_BITS_MIN_WAVES_WIDE;
+    static constexpr int value = sizeof(Pt) <= 16 ? 1 : (LOCAL_IDS ? YA_BITS_MIN_WAVES_WIDE_LOCAL : YA_BITS_MIN_WAVES_WIDE);
 };
-template<typename Pt>
+template<typename Pt, bool LOCAL_IDS = false>
 struct Pops {
-    static constexpr int value = sizeof(Pt) <= 16 ? YA_BITS_POPS : YA_BITS_POPS_WIDE;
+    static constexpr int value = sizeof(Pt) <= 16 ? YA_BITS_POPS : (LOCAL_IDS ? YA_BITS_POPS_WIDE_LOCAL : YA_BITS_POPS_WIDE);
 };
 constexpr int BLOCK = YA_BITS_BLOCK;
 constexpr int WORDS = YA_MASK_WORDS;
@@ -1008,7 +1019,8 @@ __device__ __forceinline__ void shift_in(unsigned& m, const float d2, const floa
 // One pass: up to three candidate segments [b_r, e_r) of the staged cells (LDS indices;
 // empty if b_r >= e_r), at most PASS_BITS bits after padding each to a multiple of four.
 // shift_r turns an LDS index of segment r into a slot of the sorted arrays.
-template<typename Pt, Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction, bool STAGE_V, bool GLOBAL_IDS>
+template<typename Pt, Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction, bool STAGE_V, bool GLOBAL_IDS,
+    bool LOCAL_IDS = false>
 __device__ __forceinline__ void pass(const Entry<Pt>* __restrict__ sh_e, const float4* __restrict__ sh_v,
     Lds_word* const words,
     const int b0, const int e0, const int b1, const int e1, const int b2, const int e2,
@@ -1016,7 +1028,7 @@ __device__ __forceinline__ void pass(const Entry<Pt>* __restrict__ sh_e, const f
     const Pt& Xi, const int i, const float cut2, Pt& F, float3& sum_v, float& sum_friction,
     const int* __restrict__ global_id)
 {
-    constexpr int POPS = Pops<Pt>::value;
+    constexpr int POPS = Pops<Pt, LOCAL_IDS>::value;
     // ---- phase 1 ----
     unsigned m = 0;
     int p = 0;  // bits emitted
@@ -1113,12 +1125,13 @@ __device__ __forceinline__ void pass(const Entry<Pt>* __restrict__ sh_e, const f
 
 // GLOBAL_IDS (z-slab decomposition): functors get global_id[local index]; a template parameter
 // rather than a null test so that the single-GPU kernel carries neither the test nor the gather.
+// LOCAL_IDS (wide points only): the build for a model that keeps its ids in cube order, see bits::Min_waves.
 template<typename Pt, Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction, bool STAGE_V = false,
-    bool GLOBAL_IDS = false>
+    bool GLOBAL_IDS = false, bool LOCAL_IDS = false>
 #ifdef YA_BITS_WAVES_PER_EU
 __attribute__((amdgpu_waves_per_eu(YA_BITS_WAVES_PER_EU)))
 #endif
-__global__ __launch_bounds__(bits::BLOCK, bits::Min_waves<Pt>::value) void grid_force_bits(const int n,
+__global__ __launch_bounds__(bits::BLOCK, (bits::Min_waves<Pt, LOCAL_IDS>::value)) void grid_force_bits(const int n,
     const Entry<Pt>* __restrict__ sorted, const float4* __restrict__ sorted_v,
     const int* __restrict__ cube_id, const int* __restrict__ offs, const int gs,
     const int n_cubes, const float cut2, Pt* __restrict__ d_dX, const bool has_gen,
@@ -1160,11 +1173,14 @@ __global__ __launch_bounds__(bits::BLOCK, bits::Min_waves<Pt>::value) void grid_
         const int t_hi = max(min(offs[min(part_cube_hi, n_cubes)] / FB, t_end), t_lo);
         const int mine = part == 1 ? (t_lo - t_first) + (t_end - t_hi) : t_hi - t_lo;
         if ((int)blockIdx.x >= mine) return;
-        if (part == 1) {
-            const int t = xcd_contiguous_tile<16>(blockIdx.x, mine);
+        // (part 2 as well: in the cap of a ball -- the first and the last slab -- the tiles' cost falls
+        // or rises all along the list, and two ranges per XCD, paired for a whole ball's rise and
+        // fall, left the XCD with the two dearest ranges 10 % behind)
+        const int t = xcd_contiguous_tile<16>(blockIdx.x, mine);
+        if (part == 1)
             tile = t < t_lo - t_first ? t_first + t : t_hi + (t - (t_lo - t_first));
-        } else
-            tile = t_lo + xcd_contiguous_tile(blockIdx.x, mine);
+        else
+            tile = t_lo + t;
     }
     const int s0 = tile * FB;
     const int s = s0 + threadIdx.x;
@@ -1229,7 +1245,7 @@ __global__ __launch_bounds__(bits::BLOCK, bits::Min_waves<Pt>::value) void grid_
             const int bits_needed = (max(se[0] - sb[0], 0) + 3 & ~3) + (max(se[1] - sb[1], 0) + 3 & ~3) +
                                     (max(se[2] - sb[2], 0) + 3 & ~3);
             if (!__any(bits_needed > bits::PASS_BITS)) {
-                bits::pass<Pt, pw_int, pw_friction, STAGE_V, GLOBAL_IDS>(sh_e, sh_v, words, sb[0], se[0], sb[1], se[1], sb[2],
+                bits::pass<Pt, pw_int, pw_friction, STAGE_V, GLOBAL_IDS, LOCAL_IDS>(sh_e, sh_v, words, sb[0], se[0], sb[1], se[1], sb[2],
                     se[2], shift[0], shift[1], shift[2], sorted_v, Xi, gi, cut2, F, sum_v, sum_friction,
                     global_id);
             } else {
@@ -1241,7 +1257,7 @@ __global__ __launch_bounds__(bits::BLOCK, bits::Min_waves<Pt>::value) void grid_
                     const int rs = r == 0 ? shift[0] : (r == 1 ? shift[1] : shift[2]);
 #pragma unroll 1
                     for (int b = rb; __any(b < re); b += bits::PASS_BITS)
-                        bits::pass<Pt, pw_int, pw_friction, STAGE_V, GLOBAL_IDS>(sh_e, sh_v, words, b, min(re, b + bits::PASS_BITS),
+                        bits::pass<Pt, pw_int, pw_friction, STAGE_V, GLOBAL_IDS, LOCAL_IDS>(sh_e, sh_v, words, b, min(re, b + bits::PASS_BITS),
                             0, 0, 0, 0, rs, 0, 0, sorted_v, Xi, gi, cut2, F, sum_v, sum_friction, global_id);
                 }
             }
@@ -1766,8 +1782,12 @@ struct Guard_band {
         return fabsf(z - lo_face) <= width || fabsf(z - hi_face) <= width ? 1.f : 0.5f;
     }
 };
-// partial[blockIdx.x] = the largest v of the workgroup (v >= 0, or NaN: counted as +inf); every
-// thread of an UPDATE_BLOCK-wide workgroup must call it.  For the drift guard of a z-slab.
+// The largest v of the workgroup (v >= 0, or NaN: counted as +inf) folded into one of
+// GUARD_SLOTS slots of `partial` by a non-returning atomic max (non-negative binary32 values order
+// like their bit patterns); every thread of an UPDATE_BLOCK-wide workgroup must call it.  The slots
+// are read, and zeroed again, by the reduction that follows (ya_slab_pack).  For the drift guard of
+// a z-slab: thousands of workgroups, a few dozen atomics per slot, one short list to fold.
+constexpr int GUARD_SLOTS = 256;
 __device__ __forceinline__ void block_max_to(float v, float* __restrict__ partial)
 {
     __shared__ float sh_max[UPDATE_BLOCK / 64];
@@ -1777,7 +1797,7 @@ __device__ __forceinline__ void block_max_to(float v, float* __restrict__ partia
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int w = 1; w < UPDATE_BLOCK / 64; w++) v = fmaxf(v, sh_max[w]);
-        partial[blockIdx.x] = v;
+        if (v > 0.f) atomicMax(reinterpret_cast<unsigned*>(partial) + (blockIdx.x % GUARD_SLOTS), __float_as_uint(v));
     }
 }
 }  // namespace ya
@@ -2274,8 +2294,8 @@ protected:
     // (d_total: the stage's all-reduced {sum, count pieces}; stage 1 leaves its fixed velocity in
     // d_fix_out, stage 2 reads it from there)
     // (fix_mode: ya::fix_from_total; pred_partial / z_selected + moved_partial: the drift guard's
-    // per-workgroup maxima, (n + UPDATE_BLOCK - 1) / UPDATE_BLOCK floats each, or NULL; votes_out: see
-    // heun_step_raw_total)
+    // maxima, ya::GUARD_SLOTS floats each (zeroed by the reduction that reads them), or NULL;
+    // votes_out: see heun_step_raw_total)
     bool stage1_update_in_sorted_copy(int n, float dt, const float* d_total, float* d_fix_out, int n_active,
         int fix_mode = 0, float* pred_partial = nullptr, const ya::Guard_band band = ya::Guard_band{})
     {
@@ -2295,9 +2315,9 @@ protected:
     // their count, its two votes (the drift guard brought up to date in the same kernel if
     // fold_guard), the fixed point's right-hand side if *d_fix_index is one of its cells
     struct Guard_inputs {
-        const float* moved_partial = nullptr;
+        float* moved_partial = nullptr;
         int n_moved = 0;
-        const float* pred_partial = nullptr;
+        float* pred_partial = nullptr;
         int n_pred = 0;
         float limit = 0.f, lag_steps = 0.f;
         float* state = nullptr;
@@ -2763,6 +2783,13 @@ protected:
                 }
             } else if (stage_v) {
                 YA_BITS_LAUNCH(true, false);
+            } else if (sizeof(Pt) > 16 && ids_in_cube_order) {
+                // the model renumbers its cells (Solution::renumber): the build with more wavefronts per SIMD
+                YA_FORCE_LAUNCH((ya::grid_force_bits<Pt, pw_int, pw_friction, false, false, (sizeof(Pt) > 16)>),
+                    (n + ya::bits::BLOCK - 1) / ya::bits::BLOCK, ya::bits::BLOCK, n, d_cells, d_cells_v,
+                    (const int*)grid.d_cube_id, grid.offsets(), grid.grid_size, grid.n_cubes, cut2, d_dX, has_gen, n_active,
+                    d_dX_in_cell_order, (const int*)d_global_id, part, force_part_cube_lo, force_part_cube_hi,
+                    force_own_cube_lo, force_own_cube_hi);
             } else {
                 YA_BITS_LAUNCH(false, false);
             }
@@ -2785,8 +2812,14 @@ protected:
         grid.build(n, d_X, cube_size);
         return grid.d_point_id;
     }
-    // ... after which cell s IS slot s: the next build visits the cells in storage order
-    void ids_changed() { grid.forget_order(); }
+    // ... after which cell s IS slot s: the next build visits the cells in storage order, and the
+    // force launches of wide points go to the build made for ids in cube order (bits::Min_waves)
+    void ids_changed()
+    {
+        grid.forget_order();
+        ids_in_cube_order = true;
+    }
+    bool ids_in_cube_order = false;
     // The part of the first stage's grid build that can be queued before the host knows
     // n (Heun_solver::take_step); pwints then only finishes the build.
     void begin_build(const Pt* d_X, const int* d_n, const int n_bound)

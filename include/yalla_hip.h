@@ -251,9 +251,11 @@ int ya_max_abs_diff_partials(int n);
  * max of the n_moved partials (|z - z at selection| as the previous step left the cells), predicted =
  * max of the n_pred partials (this step's predictor |dz|); error (sticky) if moved + predicted exceeds
  * `limit` (the second stage would compute with it), request if moved + lag_steps * predicted does.
+ * Both lists of partials are left zeroed (the update kernels of include/solvers.cuh fold their maxima
+ * into 256 slots by atomic max).
  * (A z-slab's mirrored cells are valid only while no cell has moved further than
  * (halo - cube_size) / 2 since they were chosen; include/slab_logic.inc.) */
-int ya_slab_guard_update(const float* d_moved_partial, int n_moved, const float* d_pred_partial, int n_pred,
+int ya_slab_guard_update(float* d_moved_partial, int n_moved, float* d_pred_partial, int n_pred,
     float limit, float lag_steps, float* d_state, void* stream);
 /* ya_reduce_sum_packed plus what else a rank puts into a stage's all-reduce: d_out[n_floats + 2] = its
  * vote for an early re-selection and [n_floats + 3] = its error vote (d_guard_state[2], [3] if
@@ -261,8 +263,8 @@ int ya_slab_guard_update(const float* d_moved_partial, int n_moved, const float*
  * fixed point's right-hand side, solvers.cuh:250-253,269-272) or zeros if that index is negative or
  * the pointer NULL, [n_floats + 7] = 0.  With fold_guard the drift guard is brought up to date first,
  * in the same kernel (ya_slab_guard_update's arguments).  d_out: n_floats + 8 floats. */
-int ya_slab_pack(const void* d_v, int n_floats, int n, float* d_out, float* d_ws, const float* d_moved_partial,
-    int n_moved, const float* d_pred_partial, int n_pred, float limit, float lag_steps, float* d_guard_state,
+int ya_slab_pack(const void* d_v, int n_floats, int n, float* d_out, float* d_ws, float* d_moved_partial,
+    int n_moved, float* d_pred_partial, int n_pred, float limit, float lag_steps, float* d_guard_state,
     int fold_guard, int with_votes, int host_error, const int* d_fix_index, void* stream);
 
 /* `bytes` (<= 4096) read back without stalling the stream that produces them: _begin queues the copy

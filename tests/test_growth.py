@@ -133,3 +133,119 @@ def test_branching_with_several_lanes_per_cell(device, lanes):
     assert counts_a == counts_b and counts_a[-1] > 3000
     assert np.array_equal(Xa.view(np.uint32), Xb.view(np.uint32))
     assert np.array_equal(ta, tb) and np.array_equal(ma, mb) and np.array_equal(ea, eb)
+
+
+# ---- Solution::renumber (opt-in, not in the reference): cells renumbered in cube order -------------
+def _state(s, n):
+    return s.positions(), s.old_v()[:n].copy(), {k: s.get_prop(k, n) for k in ("type", "mes_nbs", "epi_nbs")}
+
+
+def test_renumber_is_a_permutation_into_cube_order_oracle(oracle):
+    """renumber(type, mes_nbs, epi_nbs) on the grown system: the same multiset of cell records
+    {X, old_v, type, counters}, now stored cube by cube (what a fresh grid build would sort them to),
+    ascending old id inside a cube; a second call changes nothing."""
+    s, _ = growth_case.setup(oracle, "grid", n_max=4000)
+    growth_case.grow(s, 20)
+    n = s.get_d_n()
+    X0, v0, p0 = _state(s, n)
+    s.set_param("renumber_now", 1)
+    X1, v1, p1 = _state(s, n)
+    # the permutation, recovered from the (distinct) positions
+    key0 = {tuple(x): i for i, x in enumerate(X0.view(np.uint32).tolist())}
+    order = np.array([key0[tuple(x)] for x in X1.view(np.uint32).tolist()])
+    assert sorted(order.tolist()) == list(range(n))
+    assert np.array_equal(v1.view(np.uint32), v0[order].view(np.uint32))
+    for k in p0:
+        assert np.array_equal(p1[k], p0[k][order]), k
+    # cube order: cube id as the grid computes it (grid_size 50, cube_size 1), non-decreasing, ids ascending inside
+    cube = ((np.floor(X1[:, 0]) + 25) + (np.floor(X1[:, 1]) + 25) * 50 + (np.floor(X1[:, 2]) + 25) * 2500).astype(int)
+    assert (np.diff(cube) >= 0).all()
+    same = np.diff(cube) == 0
+    assert (np.diff(order)[same] > 0).all()
+    assert len(np.unique(cube)) < n, "test too sparse: no cube holds two cells"
+    s.set_param("renumber_now", 1)
+    X2, v2, p2 = _state(s, n)
+    assert np.array_equal(X2.view(np.uint32), X1.view(np.uint32)) and np.array_equal(p2["type"], p1["type"])
+    s.close()
+
+
+def test_renumbered_model_keeps_running_oracle(oracle):
+    """A model that renumbers every 4th step (set_param renumber_every: what its loop would do) keeps
+    its population, its two cell types and the epithelium outside; daughters are appended behind
+    the renumbered cells as before."""
+    s, _ = growth_case.setup(oracle, "grid", n_max=4000)
+    s.set_param("renumber_every", 4)
+    counts = growth_case.grow(s, 25)
+    assert counts[-1] > 200 and counts == sorted(counts)
+    n = counts[-1]
+    X = s.positions()
+    t = s.get_prop("type", n)
+    assert np.isfinite(X).all() and 0 < t.sum() < n
+    r = np.linalg.norm(X[:, :3] - X[:, :3].mean(axis=0), axis=1)
+    assert r[t == 1].mean() > r[t == 0].mean()
+    s.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", ["growth", "branching"])
+def test_renumbering_device_matches_oracle_lockstep(oracle, device, model):
+    """The same model loop with a renumbering every 3rd step on both backends, in lock-step: identical
+    cell counts, types and neighbour counters (so the permutations agree), positions to 1e-5."""
+    case = growth_case if model == "growth" else branching_case
+    so, _ = case.setup(oracle)
+    sd, _ = case.setup(device)
+    n0 = so.get_d_n()
+    for s in (so, sd):
+        s.set_param("renumber_every", 3)
+        if model == "growth":
+            s.set_param("prolif_rate", 0.05)
+            s.set_param("seed", 77)
+    for step in range(12):
+        so.take_step(0.2)
+        sd.take_step(0.2)
+        n_o, n_d = so.get_d_n(), sd.get_d_n()
+        assert n_o == n_d, f"cell counts differ at step {step}"
+        Xo, Xd = so.positions(), sd.positions()
+        scale = np.abs(Xo[:, :3]).max()
+        assert np.abs(Xo[:, :3] - Xd[:, :3]).max() <= 1e-5 * scale, step
+        for name in ("type", "mes_nbs", "epi_nbs"):
+            assert np.array_equal(so.get_prop(name, n_o), sd.get_prop(name, n_d)), (name, step)
+        sd.h_X[:] = so.h_X
+        sd.h_n = n_o
+        sd.copy_to_device()
+        sd.set_old_v(so.old_v())
+    assert so.get_d_n() > n0, "nothing divided"
+    so.close()
+    sd.close()
+
+
+@pytest.mark.gpu
+def test_renumber_moves_links_and_leaves_forces_alone(device):
+    """springs + links: renumbering permutes the cells and renames the links' endpoints; the next steps
+    then give every cell (found again by its position) the position the unrenumbered run gives it, to
+    rounding -- sums are accumulated in another order where cells have since changed cubes."""
+    from yalla_amd.solution import Solution
+    n = 20000
+    runs = []
+    for renumber in (False, True):
+        with Solution("springs_links_grid", n, 50, 1.0, lib=device) as s:
+            s.random_sphere(0.7, 11)
+            rng = np.random.default_rng(5)
+            a = rng.integers(0, n, 3000)
+            links = np.stack([a, (a + rng.integers(1, 50, 3000)) % n], axis=1).astype(np.int32)
+            s.set_links(links, 0.2)
+            s.take_step(0.002, 2)
+            before = s.positions()
+            if renumber:
+                s.set_param("renumber_now", 1)
+                after = s.positions()
+                key = {tuple(x): i for i, x in enumerate(before.view(np.uint32).tolist())}
+                order = np.array([key[tuple(x)] for x in after.view(np.uint32).tolist()])
+            else:
+                order = np.arange(n)
+            s.take_step(0.002, 3)
+            X = np.empty((n, 3), np.float32)
+            X[order] = s.positions()       # back to the original numbering
+            runs.append(X)
+    assert np.abs(runs[0] - runs[1]).max() <= 1e-5 * np.abs(runs[0]).max()
+    assert not np.array_equal(runs[0], np.zeros_like(runs[0]))

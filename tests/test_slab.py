@@ -94,7 +94,7 @@ def test_slabs_thinner_than_the_ghost_layer_are_refused(oracle):
 
 def test_native_plan_cuts_on_cube_planes_and_balances_own_plus_mirrored_cells(oracle):
     """ya::slab_plan through the C ABI against its numpy restatement: cut planes on cube-plane
-    boundaries, the largest own + 0.6 * mirrored count of a slab as small as such cuts allow,
+    boundaries, the largest own + 0.4 * mirrored count of a slab as small as such cuts allow,
     capacities from the fullest ghost layer."""
     X0, _ = reference_run(oracle, 5000, 50, 0.5, 3, 0.001, 0)
     bounds, halo_cap, mig_cap, n_max = slab_mod.slab_plan(X0, 4, 1.0, oracle)
@@ -108,7 +108,7 @@ def test_native_plan_cuts_on_cube_planes_and_balances_own_plus_mirrored_cells(or
             own = np.count_nonzero((z >= b[r]) & (z < b[r + 1]))
             ghosts = (np.count_nonzero((z >= b[r] - 1.25) & (z < b[r])) if r > 0 else 0) + \
                      (np.count_nonzero((z >= b[r + 1]) & (z < b[r + 1] + 1.25)) if r < 3 else 0)
-            costs.append(own + 0.6 * ghosts)
+            costs.append(own + 0.4 * ghosts)
         return max(costs)
 
     # the balance is within a plane of cells of what the quantile cuts (which may lie anywhere) reach
@@ -457,7 +457,7 @@ def test_eight_slabs_of_a_million_cells_native_sequencing(device):
     assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-2000:]
     out = json.loads(proc.stdout.strip().splitlines()[-1])
     assert out["world"] == 8 and len(out["slabs"]) == 8 and out["cells_after"] == n
-    assert min(s["n_own"] for s in out["slabs"]) > 0.7 * n / 8   # (cuts balance own + 0.6 mirrored cells)
+    assert min(s["n_own"] for s in out["slabs"]) > 0.7 * n / 8   # (cuts balance own + 0.4 mirrored cells)
     assert all(s["n_ghost"] > 0 for s in out["slabs"])
     par = out["parity"]
     assert par["take_steps"] == steps + warmup and par["cells_missing"] == 0

@@ -14,7 +14,7 @@ cd /tmp && export TMPDIR=/tmp
 export YALLA_REHEARSAL_MARKERS=1
 for plan in planes quantile; do
   if [ $plan = quantile ]; then export YALLA_SLAB_PLAN=quantile; fi
-  rocprofv3 --kernel-trace --stats --output-format csv -d $out/slab8_$plan -o k -- $GRAFT_REPO_ROOT/tools/slab_rehearsal 10000000 8 24 3 8 > $out/slab8_traced_$plan.json 2> $out/slab8_$plan.err
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/slab8_$plan -o k -- $GRAFT_REPO_ROOT/tools/slab_rehearsal 10000000 8 24 3 8 > $out/slab8_traced_$plan.json 2> $out/slab8_$plan.err
   SLAB_TIMELINE_RANK=4 python3 $GRAFT_REPO_ROOT/tools/slab_trace_summary.py $out/slab8_$plan/k_kernel_trace.csv 27 > $out/slab8_device_time_$plan.json 2> $out/timeline_rank4_$plan.txt
   cp $out/slab8_$plan/k_kernel_stats.csv $out/slab8_kernel_stats_$plan.csv
   rm -rf $out/slab8_$plan

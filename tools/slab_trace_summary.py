@@ -59,7 +59,18 @@ def main(path, steps, skip=0):
                            else n)
             by_kernel[short][0] += b - a
             by_kernel[short][1] += 1
+        # the force launches by themselves: boundary and interior launch of a stage start a few microseconds
+        # apart (the shorter one of such a pair is the boundary launch)
+        fl = sorted((a, b) for a, b, n in ks if "grid_force" in n)
+        pairs = [(fl[k], fl[k + 1]) for k in range(0, len(fl) - 1, 2) if fl[k + 1][0] - fl[k][0] < 50_000]
+        first = [x[1] - x[0] for x, y in pairs]
+        second = [y[1] - y[0] for x, y in pairs]
+        spans = [max(x[1], y[1]) - x[0] for x, y in pairs]
+        mean = lambda v: round(sum(v) / max(len(v), 1) / 1e3, 1)
         out["slabs"].append({"rank": r, "device_ms_per_step": busy, "force_ms_per_step": force,
+                             "force_stage_us": {"first_launch": mean(first), "second_launch": mean(second),
+                                                "span": mean(spans), "stages": len(pairs),
+                                                "span_by_stage": [round(v / 1e3) for v in spans]},
                              "copy_fill_ms_per_step": copies, "launches_per_step": len(ks) / steps,
                              "kernels_us_per_step_and_launches_per_step": {
                                  k: [round(v[0] / steps / 1e3, 1), round(v[1] / steps, 2)]
@@ -68,10 +79,12 @@ def main(path, steps, skip=0):
     # (SLAB_TIMELINE_RANK=r: one stretch of that slab's launches -- start, duration, kernel -- on stderr)
     import os
     if os.environ.get("SLAB_TIMELINE_RANK"):
-        ks = per_rank[int(os.environ["SLAB_TIMELINE_RANK"])]
-        lo = len(ks) // 2
-        for a, b, n in ks[lo:lo + 140]:
-            print(f"{(a - ks[lo][0]) / 1e3:10.1f} {(b - a) / 1e3:8.1f}  {n[:70]}", file=sys.stderr)
+        for which in os.environ["SLAB_TIMELINE_RANK"].split(","):
+            ks = per_rank[int(which)]
+            lo = len(ks) // 2
+            print(f"---- rank {which}", file=sys.stderr)
+            for a, b, n in ks[lo:lo + 140]:
+                print(f"{(a - ks[lo][0]) / 1e3:10.1f} {(b - a) / 1e3:8.1f}  {n[:70]}", file=sys.stderr)
     out["slowest_slab_device_ms_per_step"] = worst
     out["projected_speedup_device_time_only"] = out["undivided_device_ms_per_step"] / worst
     out["note"] = ("device-busy time only (no host launch gaps, no RCCL latency, no xGMI transfer time; the rehearsal's "

@@ -527,20 +527,31 @@ __global__ __launch_bounds__(BLOCK) void k_max_abs_diff(const float* __restrict_
 // get there.  Folded into the last kernel of the second stage's reduction (k_slab_pack_final), which
 // puts the votes into the all-reduce's payload; ya_slab_guard_update runs it by itself.
 struct Guard_args {
-    const float* moved_partial;
+    float* moved_partial;
     int n_moved;
-    const float* pred_partial;
+    float* pred_partial;
     int n_pred;
     float limit, lag_steps;
     float* state;  // NULL: no guard
 };
 __device__ __forceinline__ void guard_fold(const Guard_args& g, float* sh /* [4] */)
 {
-    float a = 0.f, p = 0.f;
-    for (int k = threadIdx.x; k < g.n_moved; k += BLOCK) a = fmaxf(a, g.moved_partial[k]);
-    for (int k = threadIdx.x; k < g.n_pred; k += BLOCK) p = fmaxf(p, g.pred_partial[k]);
+    // (several thousand partials, one workgroup: four independent loads in flight per thread and pass)
+    float a4[4] = {0.f, 0.f, 0.f, 0.f}, p4[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = threadIdx.x; k < g.n_moved; k += 4 * BLOCK) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) a4[u] = fmaxf(a4[u], k + u * BLOCK < g.n_moved ? g.moved_partial[k + u * BLOCK] : 0.f);
+    }
+    for (int k = threadIdx.x; k < g.n_pred; k += 4 * BLOCK) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) p4[u] = fmaxf(p4[u], k + u * BLOCK < g.n_pred ? g.pred_partial[k + u * BLOCK] : 0.f);
+    }
+    float a = fmaxf(fmaxf(a4[0], a4[1]), fmaxf(a4[2], a4[3])), p = fmaxf(fmaxf(p4[0], p4[1]), fmaxf(p4[2], p4[3]));
     a = block_max(a, sh);
     p = block_max(p, sh);
+    // (the update kernels fold their maxima into these lists by atomic max: left zeroed for the next step)
+    for (int k = threadIdx.x; k < g.n_moved; k += BLOCK) g.moved_partial[k] = 0.f;
+    for (int k = threadIdx.x; k < g.n_pred; k += BLOCK) g.pred_partial[k] = 0.f;
     if (threadIdx.x == 0) {
         g.state[0] = a;
         g.state[1] = p;
@@ -1260,8 +1271,8 @@ int ya_reduce_sum_packed(const void* d_v, int n_floats, int n, float* d_out, flo
 }
 
 
-int ya_slab_pack(const void* d_v, int n_floats, int n, float* d_out, float* d_ws, const float* d_moved_partial,
-    int n_moved, const float* d_pred_partial, int n_pred, float limit, float lag_steps, float* d_guard_state,
+int ya_slab_pack(const void* d_v, int n_floats, int n, float* d_out, float* d_ws, float* d_moved_partial,
+    int n_moved, float* d_pred_partial, int n_pred, float limit, float lag_steps, float* d_guard_state,
     int fold_guard, int with_votes, int host_error, const int* d_fix_index, void* stream)
 {
     hipStream_t st = (hipStream_t)stream;
@@ -1408,7 +1419,7 @@ int ya_max_abs_diff(const float* d_a, size_t a_stride_bytes, const float* d_b, s
     return (int)hipGetLastError();
 }
 
-int ya_slab_guard_update(const float* d_moved_partial, int n_moved, const float* d_pred_partial, int n_pred,
+int ya_slab_guard_update(float* d_moved_partial, int n_moved, float* d_pred_partial, int n_pred,
     float limit, float lag_steps, float* d_state, void* stream)
 {
     if (!d_state || n_moved < 0 || n_pred < 0 || (n_moved && !d_moved_partial) || (n_pred && !d_pred_partial))

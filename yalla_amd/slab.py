@@ -305,7 +305,7 @@ def slab_plan(X, world, cube_size=1.0, lib=None):
     return bounds, int(caps[0]), int(caps[1]), int(caps[2])
 
 
-def slab_bounds(z, world, cube_size=1.0, margin=0.25, ghost_weight=0.6, snap_to_planes=True):
+def slab_bounds(z, world, cube_size=1.0, margin=0.25, ghost_weight=0.4, snap_to_planes=True):
     """The cut planes alone: numpy restatement of ya::slab_plan_sorted (include/slab_logic.inc) for
     tests.  Cuts on the grid's cube-plane boundaries k * cube_size, chosen so that the largest
     own + ghost_weight * mirrored cell count of a slab is smallest (greedy walk under a bisected
