@@ -169,10 +169,20 @@ def parse(argv=None):
                     help="configs 3 / 4: the model calls Solution::renumber(type, mes_nbs, epi_nbs) -- new cell ids in "
                          "cube order, opt-in, not in the reference -- once before the warm-up and after every this-many-th "
                          "step (0 = never: ids stay in birth order as in the reference)")
+    ap.add_argument("--sustained", action="store_true",
+                    help="a SUSTAINED figure instead of the 20-step headline: --steps (default 3000, > 1 s) take_steps of "
+                         "the same system with dt = 0, i.e. every step recomputes the same state (forces, both grid "
+                         "builds, reductions, updates: all the work, none of the drift of the clumping springs system), "
+                         "with the shader clock sampled beside it (ya_shader_clock_mhz) so that throttling shows")
     ap.add_argument("--graph", type=int, default=0,
                     help="Heun_solver::graph_steps: 1 = replay the step as a hipGraph, -1 = below 400 k "
                          "cells only, 0 = plain launches (default)")
     args = ap.parse_args(argv)
+    if args.sustained:
+        if args.steps == 20:
+            args.steps = 3000
+        if args.dt is None:
+            args.dt = 0.0
     if args.model not in MODELS:
         ap.error(f"--model must be one of {sorted(MODELS)}")
     if args.gpus < 1:
@@ -520,10 +530,31 @@ def main(argv=None):
         # HIP events on every 5th launch of the force kernel (both stages alternate):
         # a timed launch costs a few microseconds of stream time, see DESIGN.md section 6
         sim.profile(True, every=args.time_every)
+    clock_samples = []
+    sampler = None
+    if args.sustained and rank == 0:
+        import ctypes as C
+        import threading
+        core = C.CDLL(_ffi.CORE_LIB, mode=C.RTLD_LOCAL)
+        core.ya_shader_clock_mhz.argtypes = [C.c_double, C.POINTER(C.c_double)]
+        stop_sampling = threading.Event()
+
+        def sample_clock():   # beside the steps: a wavefront of its own on a stream of its own
+            mhz = C.c_double()
+            while not stop_sampling.is_set():
+                if core.ya_shader_clock_mhz(200.0, C.byref(mhz)) == 0:
+                    clock_samples.append(mhz.value)
+                stop_sampling.wait(0.05)
+
+        sampler = threading.Thread(target=sample_clock, daemon=True)
+        sampler.start()
     t0 = time.perf_counter()
     advance(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
+    if sampler is not None:
+        stop_sampling.set()
+        sampler.join()
     if graph_mode:
         sim.profile(True, every=1)
         advance(min(args.steps, 10))
@@ -653,6 +684,16 @@ def main(argv=None):
                 "fp32_valu_peak_TFLOPs": FP32_VALU_PEAK_TFLOPS,
             },
         }
+        if args.sustained:
+            cs = sorted(clock_samples)
+            out["sustained"] = {
+                "seconds": elapsed,
+                "what": "dt = %g: every take_step does all its work on the same state (no drift of the workload)" % dt,
+                "shader_clock_mhz": {"samples": len(cs), "min": cs[0] if cs else None,
+                                     "median": cs[len(cs) // 2] if cs else None, "max": cs[-1] if cs else None,
+                                     "how": "ya_shader_clock_mhz: s_memtime against the 100 MHz wall clock, one wavefront "
+                                            "beside the run, every 50 ms"},
+            }
         if world > 1:
             out["one_gpu_same_system"] = one_gpu
             out["speedup_vs_one_gpu_same_system"] = value / one_gpu if one_gpu else None

@@ -221,12 +221,13 @@ __global__ void check_sqrt_all(unsigned first, unsigned last, unsigned long long
 // 10^6 cells, so the stencil rows a tile reads (the tiles before and after it, one
 // grid row and one grid plane away) are L2 hits.  Bijective for any grid size; a
 // wrong placement guess would cost speed, not correctness.
-__device__ __forceinline__ int xcd_eighth_tile(const int block, const int n_blocks)
+__device__ __forceinline__ int xcd_eighth_tile(const int block, const int n_blocks, const bool descending = false)
 {
     constexpr int XCDS = 8;
     const int xcd = block % XCDS, turn = block / XCDS;
     const int q = n_blocks / XCDS, r = n_blocks % XCDS;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + turn;
+    const int mine = q + (xcd < r ? 1 : 0);  // tiles of this XCD's eighth
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (descending ? mine - 1 - turn : turn);
 }
 // Each XCD gets TWO contiguous sixteenths: one from the lower half of the tiles and the
 // corresponding one from the upper half.  Tiles are in cube order (z-major), and a tile's cost
@@ -235,19 +236,43 @@ __device__ __forceinline__ int xcd_eighth_tile(const int block, const int n_bloc
 // the XCDs of the caps idle at the end of a launch while those of the equator still work.
 // Pairing sixteenth k of the lower half with sixteenth k of the upper half evens that out and
 // keeps an XCD's L2 to two contiguous ranges.
+// Round 4, OUTSIDE IN: the ranges are visited alternately from the front and from the back of the
+// list -- 0, R - 1, 1, R - 2, ... -- and those from the back are walked downwards.  The list's two
+// ends are the tips of the ball's caps, where a plane of the grid holds a few hundred cells: a tile
+// of 64 cells spans several grid rows there, its nine stencil rows stage whole planes (several
+// chunks each), and it lives two to three times as long as a tile of the interior.  With the ranges
+// in storage order the top tip came LAST: a few dozen such wavefronts running on after every other
+// had finished, 35 us at the end of a 290 us launch (the last slab of the 8-slab rehearsal, whose
+// list ends with the tip: GRBM_GUI_ACTIVE + 10 % for the same SQ_WAVE_CYCLES as the first slab's,
+// profiles/r04_slab_pmc_by_rank.json).  Now both tips are started within the first half of a
+// launch, and it ends in the middle of the list, among tiles that are all alike.
 #ifndef YA_XCD_RANGES
 #define YA_XCD_RANGES 2  /* contiguous ranges of tiles per XCD (1 = plain eighths) */
+#endif
+#ifndef YA_XCD_OUTSIDE_IN
+#define YA_XCD_OUTSIDE_IN 1  /* 0 = ranges in storage order (A/B) */
 #endif
 template<int RANGES = YA_XCD_RANGES>
 __device__ __forceinline__ int xcd_contiguous_tile(const int block, const int n_blocks)
 {
-    // parts of a multiple of 8 tiles each (block and block - k * part then sit on the same XCD);
-    // the last part takes the remainder
+    // slots of a multiple of 8 blocks each (block and block - k * part then sit on the same XCD);
+    // the last slot in time takes the remainder
     const int part = (n_blocks / RANGES) & ~7;
     if (RANGES == 1 || part == 0) return xcd_eighth_tile(block, n_blocks);
     const int p = min(block / part, RANGES - 1);
-    const int first = p * part;
-    return first + xcd_eighth_tile(block - first, p == RANGES - 1 ? n_blocks - first : part);
+    const int first_block = p * part;
+    const int len = p == RANGES - 1 ? n_blocks - first_block : part;
+#if YA_XCD_OUTSIDE_IN
+    // slot p works on range r of the list: 0, R - 1, 1, R - 2, ...; the last slot on range R / 2, which
+    // is therefore the one that holds the remainder
+    constexpr int LONG_RANGE = RANGES / 2;
+    const bool from_back = p & 1;
+    const int r = from_back ? RANGES - 1 - (p - 1) / 2 : p / 2;
+    const int start = r * part + (r > LONG_RANGE ? n_blocks - RANGES * part : 0);
+    return start + xcd_eighth_tile(block - first_block, len, from_back);
+#else
+    return first_block + xcd_eighth_tile(block - first_block, len);
+#endif
 }
 
 // Test hook: the same for ya::reciprocal (dtypes.cuh) against 1.0f / x.
@@ -343,9 +368,7 @@ __device__ __forceinline__ Pt store_rhs(
         dX.y += sum_v.y / sum_friction;
         dX.z += sum_v.z / sum_friction;
     }
-#ifndef YA_AB_NO_SCATTER  /* experiment: what the 12-byte scatter by original id costs the launch (4 %) */
     d_dX[i] = dX;
-#endif
     return dX;
 }
 
@@ -544,67 +567,6 @@ __device__ __forceinline__ int stencil_row_offset(int row, int gs)
 // Grid force (replaces compute_cube, solvers.cuh:430-463).  Thread s owns
 // sorted slot s.  offs[c] = first slot of cube c, so the cubes c-1, c, c+1 of a
 // stencil row are the contiguous slots [offs[c-1], offs[c+2]).
-//
-// grid_force_direct is the plain form (neighbours read straight from the
-// sorted array through L1/L2); it is kept as the A/B baseline for grid_force.
-template<typename Pt, Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction>
-__global__ __launch_bounds__(FORCE_BLOCK) void grid_force_direct(const int n,
-    const Entry<Pt>* __restrict__ sorted, const float4* __restrict__ sorted_v,
-    const int* __restrict__ cube_id, const int* __restrict__ offs, const int gs,
-    const int n_cubes, const float cube_size, Pt* __restrict__ d_dX, const bool has_gen,
-    const int n_active, const int* __restrict__ global_id)
-{
-    const int s = blockIdx.x * FORCE_BLOCK + threadIdx.x;
-    if (s >= n) return;
-
-    const Entry<Pt> self = sorted[s];
-    const Pt Xi = self.X;
-    const int i = self.id;
-    if (i >= n_active) return;  // ghost cell of a slab decomposition: no force needed
-    // functors see GLOBAL ids in a slab decomposition (they index per-cell model arrays)
-    const int gi = global_id ? global_id[i] : i;
-    const int c = cube_id[s];
-    Pt F = ya::zero<Pt>();
-    float3 sum_v{0.f, 0.f, 0.f};
-    float sum_friction = 0;
-    for (int row = 0; row < 9; row++) {
-        const int mid = c + stencil_row_offset(row, gs);
-        // The reference indexes cube_start/end without bounds checks
-        // (solvers.cuh:444); out-of-grid cubes are treated as empty here.
-        const int first = min(max(mid - 1, 0), n_cubes);
-        const int last = min(max(mid + 2, 0), n_cubes);
-        const int k_end = offs[last];
-        for (int k = offs[first]; k < k_end; k++) {
-            const Entry<Pt> other = sorted[k];
-            Pt r = Xi - other.X;
-            float dist = dist3(r.x, r.y, r.z);
-            if (dist >= cube_size) continue;
-
-            const int j = global_id ? global_id[other.id] : other.id;
-            F += pw_int(Xi, r, dist, gi, j);
-            float friction = pw_friction(Xi, r, dist, gi, j);
-            sum_friction += friction;
-            if (friction != 0) {
-                float4 v = sorted_v[k];
-                sum_v.x += friction * v.x;
-                sum_v.y += friction * v.y;
-                sum_v.z += friction * v.z;
-            }
-        }
-    }
-    store_rhs(d_dX, i, has_gen, F, sum_v, sum_friction);
-}
-
-// Smallest binary32 t with sqrtf(t) >= cube_size.  sqrtf is monotonic and
-// correctly rounded on host and device, so `d2 < t` is exactly the reference's
-// `dist < cube_size` (solvers.cuh:450) without a square root per candidate.
-inline float cutoff_squared(float cube_size)
-{
-    float t = cube_size * cube_size;
-    while (t > 0 && sqrtf(t) >= cube_size) t = nextafterf(t, 0.f);
-    while (sqrtf(t) < cube_size) t = nextafterf(t, INFINITY);
-    return t;
-}
 
 // The first 16 bytes of a staged cell (x, y, z and one more word).  Entries whose
 // size is a multiple of 16 bytes are read as one 16-byte LDS access: 4 LDS cycles
@@ -638,106 +600,21 @@ __device__ __forceinline__ float dist2(const Pt& a, const Pt& b)
     return fmaf(dz, dz, fmaf(dy, dy, dx * dx));
 }
 
-// Cells staged in LDS at a time (16 B per float3 cell) and the per-thread
-// hit-queue depth (one byte per queued hit): 928 * 16 B + 44 * 256 B = 26 KiB per
-// workgroup, i.e. six workgroups (24 wavefronts) per CU.  Swept on MI355X
-// (DESIGN.md §6): workgroup size, staging capacity and queue depth all sit at a
-// shallow optimum here.
-template<typename Pt>
-struct Stage_cells {
-#ifndef YA_STAGE_CELLS
-#define YA_STAGE_CELLS (3 * YA_FORCE_BLOCK + 160)
-#endif
-#ifndef YA_STAGE_CELLS_MID
-#define YA_STAGE_CELLS_MID YA_STAGE_CELLS  /* 17..32-byte entries: a plane in one chunk beats a sixth workgroup (swept) */
-#endif
-    static constexpr int value =
-        sizeof(Entry<Pt>) <= 16 ? YA_STAGE_CELLS : (sizeof(Entry<Pt>) <= 32 ? YA_STAGE_CELLS_MID : YA_STAGE_CELLS / 2);
-};
-#ifndef YA_QUEUE_DEPTH
-#define YA_QUEUE_DEPTH 44
-#endif
-constexpr int QUEUE_DEPTH = YA_QUEUE_DEPTH;
-
-// LDS-staged grid force.  A workgroup owns 256 consecutive sorted slots, i.e. a
-// run of cubes [c_lo, c_hi] along x.  For stencil row r every neighbour of every
-// cell of the workgroup lies in the contiguous slots
-// [offs[c_lo + off_r - 1], offs[c_hi + off_r + 2]); each thread's own candidates
-// are the sub-range [offs[c + off_r - 1], offs[c + off_r + 2]).  The nine rows are
-// handled as three planes (dz = 0, -1, +1: rows 0-2, 3-5, 6-8 of the reference's
-// d_nhood order).  Per plane the workgroup copies its three slot ranges into LDS
-// (coalesced 16-byte loads of {X, id}), then every thread
-//
-//   phase 1  walks its candidates in the reference's order testing d2 < cut2
-//            only, and appends one byte per hit (~15 % of the 27-cube volume lies
-//            inside the cut-off sphere) to a per-thread FIFO in LDS;
-//   phase 2  drains the FIFO: distance, functor, friction, old_v term.
-//
-// Both loops run until the slowest lane of the wavefront is done, so phase 2 is
-// kept dense by draining only once per plane (or when a FIFO could overflow):
-// a lane's hit count summed over a plane varies far less across the wavefront
-// than its hit count within one 32-candidate stretch.  Order is preserved
-// (FIFO), so every per-cell sum is accumulated in the reference's order.
-template<typename Pt, Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction>
-__global__ __launch_bounds__(FORCE_BLOCK) void grid_force(const int n,
-    const Entry<Pt>* __restrict__ sorted, const float4* __restrict__ sorted_v,
-    const int* __restrict__ cube_id, const int* __restrict__ offs, const int gs,
-    const int n_cubes, const float cut2, Pt* __restrict__ d_dX, const bool has_gen,
-    const int n_active, Pt* __restrict__ d_dX_sorted, const int* __restrict__ global_id)
+// Smallest binary32 t with sqrtf(t) >= cube_size.  sqrtf is monotonic and
+// correctly rounded on host and device, so `d2 < t` is exactly the reference's
+// `dist < cube_size` (solvers.cuh:450) without a square root per candidate.
+inline float cutoff_squared(float cube_size)
 {
-    constexpr int CAP = Stage_cells<Pt>::value;
-    __shared__ __attribute__((aligned(16))) Entry<Pt> sh_e[CAP + 8];  // slack: phase 1 reads whole groups
-    // One byte per queued hit: (row of the plane) << 6 | offset of the candidate from
-    // the lane's anchor in that row (0..63).
-    __shared__ unsigned char sh_q[QUEUE_DEPTH * FORCE_BLOCK];
+    float t = cube_size * cube_size;
+    while (t > 0 && sqrtf(t) >= cube_size) t = nextafterf(t, 0.f);
+    while (sqrtf(t) < cube_size) t = nextafterf(t, INFINITY);
+    return t;
+}
 
-    // LDS (address space 3) FIFO pointers: 32-bit address arithmetic in the hot loops
-    using Lds_byte = __attribute__((address_space(3))) unsigned char;
-    Lds_byte* const q_base = (Lds_byte*)sh_q + threadIdx.x * QUEUE_DEPTH;  // this lane's FIFO
-#ifndef YA_GROUP
-#define YA_GROUP 4
-#endif
-    Lds_byte* const q_high = q_base + (QUEUE_DEPTH - YA_GROUP);  // "nearly full" mark
-
-#ifdef YA_NO_XCD_MAPPING
-    const int s0 = blockIdx.x * FORCE_BLOCK;
-#else
-    const int s0 = xcd_contiguous_tile(blockIdx.x, gridDim.x) * FORCE_BLOCK;
-#endif
-    const int s = s0 + threadIdx.x;
-    bool active = s < n;
-    const int c_lo = cube_id[s0];
-    const int c_hi = cube_id[min(s0 + FORCE_BLOCK, n) - 1];
-
-    Pt Xi = ya::zero<Pt>();
-    int i = 0, c = c_lo;
-    if (active) {
-        const Entry<Pt> self = sorted[s];
-        Xi = self.X;
-        i = self.id;
-        c = cube_id[s];
-        active = i < n_active;  // ghost cells of a slab decomposition get no force
-    }
-    if (!__syncthreads_or(active)) return;  // a workgroup of ghosts only
-    const int gi = global_id && active ? global_id[i] : i;  // what functors see (slab mode: global ids)
-    Pt F = ya::zero<Pt>();
-    float3 sum_v{0.f, 0.f, 0.f};
-    float sum_friction = 0;
-    Lds_byte* q_tail = q_base;
-    asm volatile("" : "+v"(q_tail));
-
-    // LDS index of a staged cell -> its slot in the sorted arrays (set per chunk):
-    // old_v of an interacting neighbour is read from global memory (L1/L2 hits, the
-    // neighbours of a workgroup are a few contiguous slot ranges) rather than staged,
-    // which keeps the workgroup at 40 KiB of LDS = four workgroups per CU.
-    int slot_shift0 = 0, slot_shift1 = 0, slot_shift2 = 0;
-    int anchor0 = 0, anchor1 = 0, anchor2 = 0;  // LDS index a queued offset is relative to
-    int slot0 = 0, slot1 = 0, slot2 = 0;        // the same anchors as slots of the sorted arrays
-
-    // Row bounds of a plane: six workgroup-uniform and six per-lane reads of offs[].
-    // Those of plane p + 1 are requested while plane p computes, so that a plane's
-    // staging loads do not queue behind a round trip to L2 for its bounds.
-    int next_lo[3], next_hi[3], next_begin[3], next_end[3];
+// Row bounds of a plane of the stencil for a workgroup that owns the cubes [c_lo, c_hi] and a lane in
+// cube c: six workgroup-uniform and six per-lane reads of offs[].  Those of plane p + 1 are requested
+// while plane p computes, so that a plane's staging loads do not queue behind a round trip to L2 for
+// its bounds.  Expects next_lo / next_hi / next_begin / next_end [3], c_lo, c_hi, c, gs, n_cubes, offs.
 #define YA_ROW_BOUNDS(plane_)                                                          \
     _Pragma("unroll") for (int r = 0; r < 3; r++)                                      \
     {                                                                                  \
@@ -749,145 +626,12 @@ __global__ __launch_bounds__(FORCE_BLOCK) void grid_force(const int n,
         next_begin[r] = offs[min(max(c + off - 1, 0), n_cubes)];                       \
         next_end[r] = offs[min(max(c + off + 2, 0), n_cubes)];                         \
     }
-    YA_ROW_BOUNDS(0)
-    for (int plane = 0; plane < 3; plane++) {
-        // The plane's three rows, concatenated: row r occupies [v0[r], v0[r+1]).
-        int wg_begin[3], v0[4], k_begin[3], k_end[3];
-        v0[0] = 0;
-#pragma unroll
-        for (int r = 0; r < 3; r++) {
-            wg_begin[r] = next_lo[r];
-            v0[r + 1] = v0[r] + next_hi[r] - wg_begin[r];
-            k_begin[r] = next_begin[r];
-            k_end[r] = active ? next_end[r] : k_begin[r];
-        }
-        if (plane < 2) { YA_ROW_BOUNDS(plane + 1) }
-        const int total = v0[3];
 
-        for (int chunk = 0; chunk < total; chunk += CAP) {
-            const int chunk_n = min(CAP, total - chunk);
-            __syncthreads();
-            for (int t = threadIdx.x; t < chunk_n; t += FORCE_BLOCK) {
-                const int v = chunk + t;
-                const int shift = v >= v0[2] ? wg_begin[2] - v0[2]
-                                             : (v >= v0[1] ? wg_begin[1] - v0[1] : wg_begin[0]);
-                sh_e[t] = sorted[v + shift];
-            }
-            __syncthreads();
-            slot_shift0 = wg_begin[0] + chunk;
-            slot_shift1 = wg_begin[1] - v0[1] + chunk;
-            slot_shift2 = wg_begin[2] - v0[2] + chunk;
-
-            // One wavefront-uniform loop over the plane's rows.  Phase 1: each lane
-            // walks its candidates of the current row, four per trip (their LDS reads
-            // in flight together), until done or its FIFO is nearly full; when every
-            // lane is done the wavefront moves to the next row; phase 2 drains the
-            // FIFOs when a lane is full or the plane is finished.
-            Lds_byte* const q_last = q_base + (QUEUE_DEPTH - 1);
-            int row = 0;
-            int t = max(k_begin[0] - wg_begin[0], chunk) - chunk;
-            int b = min(k_end[0] - wg_begin[0], chunk + chunk_n) - chunk;
-            anchor0 = t;
-            slot0 = t + slot_shift0;
-            int off = 0;  // t - anchor of the row; a queued byte is (row << 6) | off
-            while (true) {
-                while (t + YA_GROUP <= b && q_tail <= q_high && off + YA_GROUP <= 64) {
-                    float4 w[YA_GROUP];
-                    float d2[YA_GROUP];
-
-#pragma unroll
-                    for (int u = 0; u < YA_GROUP; u++) w[u] = staged_words(&sh_e[t + u]);
-#pragma unroll
-                    for (int u = 0; u < YA_GROUP; u++) {
-                        d2[u] = dist2_to(Xi, w[u]);
-                        keep_wide(w[u]);
-                    }
-                    // the byte is always written and only kept (tail advanced) on a hit:
-                    // no branch, no exec masking
-#pragma unroll
-                    for (int u = 0; u < YA_GROUP; u++) {
-                        *q_tail = (unsigned char)((row << 6) + off + u);
-                        q_tail += d2[u] < cut2;
-                    }
-                    t += YA_GROUP;
-                    off += YA_GROUP;
-                }
-                while (t < b && q_tail <= q_last && off < 64 &&
-                       (t + YA_GROUP > b || q_tail > q_high || off + YA_GROUP > 64)) {
-                    const float4 w = staged_words(&sh_e[t]);
-                    keep_wide(w);
-                    *q_tail = (unsigned char)((row << 6) + off);
-                    q_tail += dist2_to(Xi, w) < cut2;
-                    t++;
-                    off++;
-                }
-                const bool row_done = !__any(t < b);
-                if (row_done && row < 2) {
-                    row++;
-                    const int kb = row == 1 ? k_begin[1] - wg_begin[1] + v0[1]
-                                            : k_begin[2] - wg_begin[2] + v0[2];
-                    const int ke = row == 1 ? k_end[1] - wg_begin[1] + v0[1]
-                                            : k_end[2] - wg_begin[2] + v0[2];
-                    t = max(kb, chunk) - chunk;
-                    b = min(ke, chunk + chunk_n) - chunk;
-                    off = 0;
-                    if (row == 1) {
-                        anchor1 = t;
-                        slot1 = t + slot_shift1;
-                    } else {
-                        anchor2 = t;
-                        slot2 = t + slot_shift2;
-                    }
-                    continue;
-                }
-                {  // phase 2: drain this lane's FIFO (no lambda: nothing may have its address
-                   // taken here, the byte stores of phase 1 could alias it)
-                const int count = (int)(q_tail - q_base);
-                q_tail = q_base;
-                asm volatile("" : "+v"(q_tail));  // keep the tail an address, not base + count
-                int e_next = q_base[0];  // read one hit ahead: one LDS latency per trip, not two
-                for (int q = 0; q < count; q++) {
-                    const int e = e_next;
-                    e_next = q_base[min(q + 1, QUEUE_DEPTH - 1)];
-                    const int t = (e & 63) + (e >= 128 ? anchor2 : (e >= 64 ? anchor1 : anchor0));
-                    const Entry<Pt> other = sh_e[t];
-                    const unsigned slot = (e & 63) + (e >= 128 ? slot2 : (e >= 64 ? slot1 : slot0));
-                    const float4 v = sorted_v[slot];
-                    Pt r = Xi - other.X;
-                    float dist = dist3(r.x, r.y, r.z);
-                    const int j = global_id ? global_id[other.id] : other.id;
-                    F += pw_int(Xi, r, dist, gi, j);
-                    float friction = pw_friction(Xi, r, dist, gi, j);
-                    sum_friction += friction;
-                    if (friction != 0) {
-                        sum_v.x += friction * v.x;
-                        sum_v.y += friction * v.y;
-                        sum_v.z += friction * v.z;
-                    }
-                }
-                }
-                if (row_done) break;
-                // FIFOs are empty: lanes still inside this row re-anchor at their position
-                off = 0;
-                if (row == 0) {
-                    anchor0 = t;
-                    slot0 = t + slot_shift0;
-                } else if (row == 1) {
-                    anchor1 = t;
-                    slot1 = t + slot_shift1;
-                } else {
-                    anchor2 = t;
-                    slot2 = t + slot_shift2;
-                }
-            }
-        }
-    }
-    if (active) {
-        const Pt dX = store_rhs(d_dX, i, has_gen, F, sum_v, sum_friction);
-        if (d_dX_sorted) d_dX_sorted[s] = dX;  // for the sorted-space Euler stage
-    }
-}
-
+}  // namespace ya
+#ifdef YA_EXPERIMENTAL_FORCE_VARIANTS
+#include "experimental/force_variants.cuh"  // grid_force_direct, grid_force (byte FIFO): A/B baselines for tests and tools
+#endif
+namespace ya {
 
 // ---------------------------------------------------------------------------------
 // grid_force_bits (the default): the same two-phase kernel with the hit list kept as a BIT
@@ -926,16 +670,13 @@ template<typename Pt, Pairwise_friction<Pt> pw_friction>
 __device__ __forceinline__ void pair_friction(const Pt& Xi, const Pt& r, const float dist, const int i,
     const int j, const float4& v, float3& sum_v, float& sum_friction)
 {
-#ifndef YA_NO_FRICTION_SPECIAL
     if constexpr (pw_friction == &friction_w_neighbour<Pt>) {
         const bool nb = (i != j) & (dist < 1.f);
         sum_friction += nb ? 1.f : 0.f;
         sum_v.x += nb ? v.x : 0.f;
         sum_v.y += nb ? v.y : 0.f;
         sum_v.z += nb ? v.z : 0.f;
-    } else
-#endif
-    {
+    } else {
         const float friction = pw_friction(Xi, r, dist, i, j);
         sum_friction += friction;
         if (friction != 0) {
@@ -946,8 +687,11 @@ __device__ __forceinline__ void pair_friction(const Pt& Xi, const Pt& r, const f
     }
 }
 
-#ifdef YA_BITS_TRACE
-__device__ unsigned long long* ya_bits_trace = nullptr;  // experiment: per-workgroup time stamps
+// Hooks of tools/micro/force_trace.hip (when and where every workgroup of a launch ran): empty
+// unless include/experimental/force_trace.cuh was included first.
+#ifndef YA_BITS_PROBE_BEGIN
+#define YA_BITS_PROBE_BEGIN
+#define YA_BITS_PROBE_END(tile_)
 #endif
 namespace bits {
 #ifndef YA_BITS_BLOCK
@@ -1128,9 +872,6 @@ __device__ __forceinline__ void pass(const Entry<Pt>* __restrict__ sh_e, const f
 // LOCAL_IDS (wide points only): the build for a model that keeps its ids in cube order, see bits::Min_waves.
 template<typename Pt, Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction, bool STAGE_V = false,
     bool GLOBAL_IDS = false, bool LOCAL_IDS = false>
-#ifdef YA_BITS_WAVES_PER_EU
-__attribute__((amdgpu_waves_per_eu(YA_BITS_WAVES_PER_EU)))
-#endif
 __global__ __launch_bounds__(bits::BLOCK, (bits::Min_waves<Pt, LOCAL_IDS>::value)) void grid_force_bits(const int n,
     const Entry<Pt>* __restrict__ sorted, const float4* __restrict__ sorted_v,
     const int* __restrict__ cube_id, const int* __restrict__ offs, const int gs,
@@ -1187,10 +928,7 @@ __global__ __launch_bounds__(bits::BLOCK, (bits::Min_waves<Pt, LOCAL_IDS>::value
     bool active = s < n;
     const int c_lo = cube_id[s0];
     const int c_hi = cube_id[min(s0 + FB, n) - 1];
-#ifdef YA_BITS_TRACE
-    unsigned long long trace_t0;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(trace_t0)::"memory");
-#endif
+    YA_BITS_PROBE_BEGIN
 
     Pt Xi = ya::zero<Pt>();
     int i = 0, c = c_lo;
@@ -1267,22 +1005,7 @@ __global__ __launch_bounds__(bits::BLOCK, (bits::Min_waves<Pt, LOCAL_IDS>::value
         const Pt dX = store_rhs(d_dX, i, has_gen, F, sum_v, sum_friction);
         if (d_dX_sorted) d_dX_sorted[s] = dX;  // for the sorted-space Euler stage
     }
-#ifdef YA_BITS_TRACE
-    {   // experiment: when and where this workgroup ran (ya_bits_trace: 4 words per block)
-        unsigned long long trace_t1;
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(trace_t1)::"memory");
-        unsigned hw_id, xcc_id;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
-        if (threadIdx.x == 0 && ya_bits_trace) {
-            unsigned long long* out = ya_bits_trace + 4ull * blockIdx.x;
-            out[0] = trace_t0;
-            out[1] = trace_t1;
-            out[2] = ((unsigned long long)xcc_id << 32) | hw_id;
-            out[3] = (unsigned long long)tile;
-        }
-    }
-#endif
+    YA_BITS_PROBE_END(tile)
 }
 
 // ---------------------------------------------------------------------------------
@@ -2794,7 +2517,9 @@ protected:
                 YA_BITS_LAUNCH(false, false);
             }
 #undef YA_BITS_LAUNCH
-        } else if (force_variant == 0) {
+        }
+#ifdef YA_EXPERIMENTAL_FORCE_VARIANTS
+        else if (force_variant == 0) {
             YA_FORCE_LAUNCH((ya::grid_force_direct<Pt, pw_int, pw_friction>), blocks, ya::FORCE_BLOCK, n,
                 d_cells, d_cells_v, (const int*)grid.d_cube_id, grid.offsets(), grid.grid_size,
                 grid.n_cubes, cube_size, d_dX, has_gen, n_active, (const int*)d_global_id);
@@ -2803,6 +2528,13 @@ protected:
                 d_cells_v, (const int*)grid.d_cube_id, grid.offsets(), grid.grid_size, grid.n_cubes,
                 cut2, d_dX, has_gen, n_active, d_dX_in_cell_order, (const int*)d_global_id);
         }
+#else
+        else {
+            fprintf(stderr, "yalla-hip: Grid_computer::force_variant %d is an A/B baseline kept in "
+                            "include/experimental/force_variants.cuh: compile with -DYA_EXPERIMENTAL_FORCE_VARIANTS\n", force_variant);
+            abort();
+        }
+#endif
 #undef YA_COOP_LAUNCH
 #undef YA_FORCE_LAUNCH
     }

@@ -74,6 +74,13 @@ int ya_n_reader_destroy(ya_n_reader* r);
 int ya_n_read_begin(ya_n_reader* r, const int* d_n, void* stream);
 int ya_n_read_end(ya_n_reader* r, int* n_out);
 
+/* The shader clock in MHz as the chip runs it NOW: one wavefront on a stream of its own counts
+ * s_memtime ticks (shader cycles) against wall_clock64 (constant 100 MHz) for `microseconds`,
+ * beside whatever else is running.  Measurement aid (bench.py --sustained: MI355X drops from 2.4 to
+ * ~1.7 GHz under dense VALU issue, and a throughput figure without the clock it was taken at says
+ * little); blocks the calling thread for about that long.  No counterpart in the reference. */
+int ya_shader_clock_mhz(double microseconds, double* mhz_out);
+
 /* ---- Uniform grid (spatial hash) -------------------------------------- */
 
 typedef struct ya_grid ya_grid;

@@ -18,7 +18,7 @@ rows = []
 with Solution("springs_grid", n, gs, 1.0) as sim:
     sim.random_sphere(0.5, 42)
     done = 0
-    for upto in (0, 3, 23, 43, 63, 103, 203, 503):
+    for upto in (0, 3, 23, 43, 63, 103, 203):  # (soon after, the collapsing system throws a cell out of any grid)
         if upto > done:
             sim.take_step(0.001, upto - done)
             done = upto

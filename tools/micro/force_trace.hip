@@ -1,8 +1,10 @@
-// When and where every workgroup of one grid_force_bits launch ran (-DYA_BITS_TRACE builds of the
-// kernel stamp s_memtime at entry and exit and the hardware ids): force_trace [cells] [warm steps] > stamps.csv
+// When and where every workgroup of one grid_force_bits launch ran (include/experimental/force_trace.cuh
+// fills the kernel's probe hooks: s_memtime at entry and exit and the hardware ids): force_trace [cells] [warm steps] > stamps.csv
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+
+#include "experimental/force_trace.cuh"  // before solvers.cuh: the probe hooks of grid_force_bits
 
 #include "dtypes.cuh"
 #include "inits.cuh"
@@ -43,7 +45,7 @@ int main(int argc, char** argv)
     (void)hipMemset(d_trace, 0, (size_t)blocks * 4 * sizeof(unsigned long long));
     for (int k = 0; k < 3; k++) cells.run(n, d_out, d_outs);  // warm caches, no stamps
     (void)hipDeviceSynchronize();
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(ya::ya_bits_trace), &d_trace, sizeof(d_trace));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(ya_bits_trace), &d_trace, sizeof(d_trace));
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);

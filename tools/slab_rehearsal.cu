@@ -113,6 +113,13 @@ struct Shared {
     int world;
     Barrier barrier;
     std::mutex gpu;  // whoever holds it has the device to itself
+    // YALLA_REHEARSAL_ROTATE=1: the order in which the slabs take the GPU inside a round (a round = every
+    // slab's stretch between two transport calls) rotates from round to round -- slab (k + r) % world is
+    // the r-th of round k -- instead of being left to the mutex.  (Built to test whether the last slab's
+    // dearer force launches came from running last on a throttled chip.  They did not: same times.)
+    std::condition_variable turn_cv;
+    long next_slot = 0;
+    bool rotate = false;
     std::vector<const void*> send_lo, send_hi;
     std::vector<float*> sums;
     bool timing = false;
@@ -130,6 +137,7 @@ struct Rank {
                                              // eight threads share this box's cores with everything else)
     long message_bytes = 0;  // right-hand-side messages sent during the timed steps
     int step_index = 0;      // timed steps taken so far
+    long starts = 0;  // stretches begun so far (the same on every slab at the same point of a step)
     void stop()  // the device is drained, the clock stopped, the GPU handed on
     {
         (void)hipDeviceSynchronize();
@@ -140,11 +148,25 @@ struct Rank {
             per_step[segment][step_index] += span;
         }
         segment++;
-        shared->gpu.unlock();
+        if (shared->rotate) {
+            {
+                std::lock_guard<std::mutex> lock(shared->gpu);
+                shared->next_slot++;
+            }
+            shared->turn_cv.notify_all();
+        } else
+            shared->gpu.unlock();
     }
     void start()
     {
-        shared->gpu.lock();
+        if (shared->rotate) {
+            const int world = shared->world;
+            const long round = starts++;
+            const long slot = round * world + ((rank - round % world) % world + world) % world;
+            std::unique_lock<std::mutex> lock(shared->gpu);
+            shared->turn_cv.wait(lock, [&] { return shared->next_slot == slot; });
+        } else
+            shared->gpu.lock();
         if (shared->markers) mark(rank);
         started = Clock::now();
     }
@@ -228,6 +250,7 @@ int main(int argc, char** argv)
     }
     Shared shared{world};
     shared.markers = getenv("YALLA_REHEARSAL_MARKERS") != nullptr;
+    shared.rotate = getenv("YALLA_REHEARSAL_ROTATE") != nullptr;
     std::vector<std::unique_ptr<Slab>> slabs;
     std::vector<Rank> ranks(world);
     // One stream for every slab's interior launch (they take turns on the GPU anyway): a rank with a
@@ -336,10 +359,12 @@ int main(int argc, char** argv)
         critical += seg_max[g];
         critical_mean += mean_max;
     }
-    printf("{\"cells\": %d, \"world\": %d, \"grid_size\": %d, \"steps\": %d, \"warmup\": %d, \"migrate_every\": %d, \"cuts_on_cube_planes\": %s, "
+    printf("{\"cells\": %d, \"world\": %d, \"grid_size\": %d, \"steps\": %d, \"warmup\": %d, \"migrate_every\": %d, \"cuts\": \"%s\", "
            "\"sequencing\": \"native (Slab_grid_solver::take_step), one host thread per slab, slabs take turns on the GPU\", "
            "\"undivided_ms_per_step\": %.4f, \"halo_cap\": %d, \"slabs\": [",
-        n, world, gs, steps, warmup, migrate_every, plan.snapped ? "true" : "false", whole_ms, plan.halo_cap);
+        n, world, gs, steps, warmup, migrate_every,
+        getenv("YALLA_SLAB_PLAN") && getenv("YALLA_SLAB_PLAN")[0] == 'q' ? "z-quantiles (equal own cells)" : "own + 0.26 mirrored cells balanced",
+        whole_ms, plan.halo_cap);
     long total_own = 0;
     for (int r = 0; r < world; r++) {
         double sum = 0;

@@ -477,6 +477,25 @@ __global__ __launch_bounds__(BLOCK) void k_append_rows(float* __restrict__ dst, 
 }
 
 
+// --- the shader clock, measured --------------------------------------------------------------
+// One wavefront watches s_memtime (shader cycles) against wall_clock64 (a constant 100 MHz counter)
+// for `ticks` wall ticks: the clock the chip runs at NOW, beside whatever else it is running.
+__global__ void k_shader_clock(unsigned long long ticks, unsigned long long* out)
+{
+    if (threadIdx.x != 0) return;
+    unsigned long long c0, c1;
+    const unsigned long long w0 = wall_clock64();
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c0)::"memory");
+    unsigned long long w1 = w0;
+    while (w1 - w0 < ticks) {
+        __builtin_amdgcn_s_sleep(8);
+        w1 = wall_clock64();
+    }
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c1)::"memory");
+    out[0] = c1 - c0;
+    out[1] = w1 - w0;
+}
+
 // --- z-slab decomposition: drift guard, fixed point, a stage's all-reduce payload -------------
 __device__ __forceinline__ float block_max(float v, float* sh /* [4] */)
 {
@@ -1427,6 +1446,21 @@ int ya_slab_guard_update(float* d_moved_partial, int n_moved, float* d_pred_part
     k_slab_guard<<<1, BLOCK, 0, (hipStream_t)stream>>>(
         Guard_args{d_moved_partial, n_moved, d_pred_partial, n_pred, limit, lag_steps, d_state});
     return (int)hipGetLastError();
+}
+
+int ya_shader_clock_mhz(double microseconds, double* mhz_out)
+{
+    if (!mhz_out || !(microseconds > 0) || microseconds > 1e5) return (int)hipErrorInvalidValue;
+    static hipStream_t stream = nullptr;           // of its own, so that it runs BESIDE the work it watches
+    static unsigned long long* h_out = nullptr;    // pinned, written by the kernel itself
+    if (!stream) {
+        YA_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        YA_TRY(hipHostMalloc((void**)&h_out, 2 * sizeof(unsigned long long), hipHostMallocDefault));
+    }
+    k_shader_clock<<<1, 64, 0, stream>>>((unsigned long long)(microseconds * 100.0), h_out);
+    YA_TRY(hipStreamSynchronize(stream));
+    *mhz_out = h_out[1] ? 100.0 * (double)h_out[0] / (double)h_out[1] : 0.0;
+    return 0;
 }
 
 // A few bytes read back without stalling the stream they are produced on: queued behind the

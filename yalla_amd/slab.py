@@ -305,68 +305,59 @@ def slab_plan(X, world, cube_size=1.0, lib=None):
     return bounds, int(caps[0]), int(caps[1]), int(caps[2])
 
 
-def slab_bounds(z, world, cube_size=1.0, margin=0.25, ghost_weight=0.4, snap_to_planes=True):
+def slab_bounds(z, world, cube_size=1.0, margin=0.25, ghost_weight=0.26):
     """The cut planes alone: numpy restatement of ya::slab_plan_sorted (include/slab_logic.inc) for
-    tests.  Cuts on the grid's cube-plane boundaries k * cube_size, chosen so that the largest
-    own + ghost_weight * mirrored cell count of a slab is smallest (greedy walk under a bisected
-    bound; interior slabs at least two planes thick); the z-quantiles of rounds 1-3 when the system
-    has too few planes for that."""
+    tests.  Cuts at cells' z such that the largest own + ghost_weight * mirrored cell count of a slab
+    is smallest (greedy walk under a bisected bound); ghost_weight 0: the z-quantiles of rounds 1-3."""
     f32 = np.float32
     z = np.sort(np.asarray(z, dtype=f32))
     n = len(z)
-    cs, halo = f32(cube_size), f32(cube_size) * (f32(1.0) + f32(margin))
+    halo = f32(cube_size) * (f32(1.0) + f32(margin))
+    w = float(f32(ghost_weight))
 
     def below(v):
         return int(np.searchsorted(z, f32(v), side="left"))
 
-    quantiles = np.array([-np.inf] + [z[(n * r) // world] for r in range(1, world)] + [np.inf], dtype=f32)
-    if not snap_to_planes or world <= 1 or n == 0:
-        return quantiles
-    k_lo, k_hi = int(np.floor(z[0] / cs)), int(np.floor(z[-1] / cs)) + 1
-    planes = k_hi - k_lo
-    if planes < 2 * world - 2 or planes > 4096:
-        return quantiles
-    at, under, over = [], [], []
-    for k in range(planes + 1):
-        f = f32(k_lo + k) * cs
-        at.append(n if k == planes else below(f))
-        under.append(at[k] - below(f - halo))
-        over.append(below(f + halo) - at[k])
-    at[0] = 0
+    quantiles = [(n * r) // world for r in range(world + 1)]
+    best = quantiles
+    if w > 0 and world > 1 and n >= world:
+        def cost(a, b):
+            ghosts = 0
+            if a > 0:
+                ghosts += a - below(z[a] - halo)
+            if b < n:
+                ghosts += below(z[b] + halo) - b
+            return float(b - a) + w * ghosts
 
-    def cost(a, b):
-        ghosts = (under[a] if a > 0 else 0) + (over[b] if b < planes else 0)
-        return float(at[b] - at[a]) + float(f32(ghost_weight)) * ghosts
+        def fits(T):
+            cut = [0]
+            for r in range(world - 1):
+                a = cut[r]
+                lo, hi = a + 1, n - (world - 1 - r)
+                if lo > hi or cost(a, lo) > T:
+                    return None
+                while lo < hi:
+                    mid = lo + (hi - lo + 1) // 2
+                    if cost(a, mid) <= T:
+                        lo = mid
+                    else:
+                        hi = mid - 1
+                cut.append(lo)
+            cut.append(n)
+            return cut if cost(cut[world - 1], n) <= T else None
 
-    def fits(T):
-        cuts = [0]
-        for r in range(world):
-            a = cuts[r]
-            if r + 1 == world:
-                cuts.append(planes)
-                return cuts if planes - a >= 1 and cost(a, planes) <= T else None
-            b_max = planes - 1 - 2 * (world - 2 - r)
-            b_min = a + (1 if r == 0 else 2)
-            b = b_max
-            while b >= b_min and cost(a, b) > T:
-                b -= 1
-            if b < b_min:
-                return None
-            cuts.append(b)
-        return cuts
-
-    lo, hi = 0.0, float(n) * (1.0 + 2.0 * float(f32(ghost_weight))) + 1.0
-    best = fits(hi)
-    if best is None:
-        return quantiles
-    for _ in range(60):
-        mid = 0.5 * (lo + hi)
-        cuts = fits(mid)
-        if cuts is not None:
-            hi, best = mid, cuts
-        else:
-            lo = mid
-    return np.array([-np.inf] + [f32(k_lo + best[r]) * cs for r in range(1, world)] + [np.inf], dtype=f32)
+        lo, hi = 0.0, float(n) * (1.0 + 2.0 * w) + 1.0
+        cut = fits(hi)
+        if cut is not None:
+            best = cut
+            for _ in range(50):
+                mid = 0.5 * (lo + hi)
+                cut = fits(mid)
+                if cut is not None:
+                    hi, best = mid, cut
+                else:
+                    lo = mid
+    return np.array([-np.inf] + [z[min(best[r], n - 1)] for r in range(1, world)] + [np.inf], dtype=f32)
 
 
 class Slab:
