@@ -312,6 +312,13 @@ int ya_comm_create(const void* id_128_bytes, int rank, int world, ya_comm** out)
  * left device 0 itself or YALLA_KEEP_DEVICE=1: one process per GPU, RCCL refuses two ranks on
  * one.  Returns 997 if that device cannot be selected, 998 for rendezvous failures. */
 int ya_comm_create_from_env(int port_offset, ya_comm** out);
+/* `world` communicators for the slabs of ONE process on one GPU (out: an array of `world` handles): the
+ * same entry points below, stream-ordered like RCCL's -- messages are device-to-device copies behind
+ * the sender's stream, a send completes when its receiver has the data, the all-reduce is a kernel
+ * that sums in rank order -- with every communicator driven by a host thread of its own.  For running
+ * the decomposed step's asynchronous choreography against real peers where RCCL cannot (it refuses
+ * two ranks on one GPU): tests/test_slab.py.  Destroy every handle. */
+int ya_comm_create_loopback(int world, ya_comm** out);
 int ya_comm_destroy(ya_comm* comm);
 int ya_comm_rank(const ya_comm* comm);
 int ya_comm_world(const ya_comm* comm);

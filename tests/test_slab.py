@@ -505,3 +505,34 @@ def test_slabs_of_five_float_points_device(device):
     """The same on the device: 20-byte rows in the right-hand-side messages, the sorted-copy
     predictor and the raw corrector instantiated for Po_cell."""
     assert check(device, 40000, 3, 6, 0.002, device="hip", model="relu_po_grid") >= 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,model", [(2, "springs_grid"), (4, "springs_grid"), (3, "relu_po_grid")])
+def test_asynchronous_path_against_peers_on_one_gpu(device, world, model):
+    """The decomposed step's stream choreography with real peers: every slab's exchange of right-hand
+    sides runs on its own communication stream between two events, beside the interior launch on a
+    third stream, the all-reduce and the update wait for it (Slab_grid_solver::stage_exchange /
+    stage_join) -- the path `bench.py --gpus N` takes over RCCL.  RCCL refuses two ranks on one GPU, so
+    the peers are loopback communicators (ya_comm_create_loopback: stream-ordered copies and a kernel
+    all-reduce, a host thread per slab).  Bit for bit what the blocking callback transport gives, whose
+    calls end with the data in place; migration and re-selection included."""
+    n, dt, steps = 60000, 0.002, 9
+    X0, _ = reference_run(device, n, 50, 0.5, 3, dt, 0, model=model)
+    results = []
+    for asynchronous in (False, True):
+        plan = slab_mod.slab_plan(X0, world, 1.0, device)
+        slabs = [slab_mod.Slab(model, X0, r, world, 50, lib=device, plan=plan) for r in range(world)]
+        comms = slab_mod.loopback_comms(world) if asynchronous else None
+        slab_mod.run_slabs(slabs, dt, steps, migrate_every=3, device_memory=True, comms=comms)
+        X = np.full_like(X0, np.nan)
+        for s in slabs:
+            gid, Xr = s.own_cells()
+            X[gid] = Xr
+            s.close()
+        if comms:
+            for c in comms:
+                c.close()
+        assert not np.isnan(X).any()
+        results.append(X)
+    assert np.array_equal(results[0].view(np.uint32), results[1].view(np.uint32))

@@ -75,7 +75,7 @@ CORE_ABI = [
     "ya_n_read_begin", "ya_n_read_end", "ya_grid_status", "ya_reduce_mean", "ya_reduce_sum_packed",
     "ya_reduce_workspace_bytes", "ya_select_z", "ya_select_workspace_bytes", "ya_gather_rows",
     "ya_gather_rows_pair",
-    "ya_append_rows", "ya_comm_unique_id", "ya_comm_create", "ya_comm_create_from_env",
+    "ya_append_rows", "ya_comm_unique_id", "ya_comm_create", "ya_comm_create_loopback", "ya_comm_create_from_env",
     "ya_comm_destroy", "ya_comm_rank", "ya_comm_world", "ya_comm_exchange", "ya_comm_exchange_v",
     "ya_comm_allreduce_sum", "ya_comm_allreduce_host", "ya_comm_self_exchange",
     "ya_shader_clock_mhz", "ya_grid_set_cube_range", "ya_grid_forget_order", "ya_copy_component", "ya_pack_cells", "ya_append_cells", "ya_fill_holes", "ya_find_id", "ya_max_abs_diff", "ya_max_abs_diff_partials",

@@ -21,7 +21,10 @@
 #include <sys/socket.h>
 #include <unistd.h>
 
+#include <condition_variable>
+#include <mutex>
 #include <string>
+#include <vector>
 
 #include "yalla_hip.h"
 
@@ -151,11 +154,171 @@ int recv_all(int fd, void* data, size_t bytes)
 
 }  // namespace
 
+// ---- loopback communicators: the slabs of ONE process, on one GPU -----------------------------
+// ya_comm_create_loopback makes `world` communicators whose messages are device-to-device copies and
+// whose all-reduce is a kernel -- all of it STREAM-ORDERED like RCCL's: a call returns once its
+// work is queued, a receive lands when the sender's stream has got to its send, a send completes
+// (in stream order) when the receiver has taken the data.  Every communicator is driven by its own
+// host thread, as a rank's process would drive RCCL; the threads only rendezvous to hand each other
+// the events to wait on.  What it is for: the decomposed step's asynchronous choreography
+// (Slab_grid_solver::stage_exchange: event -> exchange on the communication stream beside the
+// interior launch -> event -> join) needs a peer to run against, RCCL refuses two ranks on one GPU,
+// and the boxes of this build have one GPU.  A test transport; nothing in it is specific to slabs.
+struct Loop_group {
+    static constexpr int RING = 8;
+    struct Post {  // what a rank hands its peers in one phase of one operation
+        const void* send_lo = nullptr;
+        const void* send_hi = nullptr;
+        size_t send_lo_bytes = 0, send_hi_bytes = 0;
+        hipEvent_t event = nullptr;  // recorded in the poster's stream at that point
+        double host_values[64];
+    };
+    struct Mail {
+        long tag = -1;  // the highest phase posted so far (phases are numbered alike on every rank)
+        Post ring[RING];
+        hipEvent_t events[RING] = {};
+        // all-reduce: "I have read every slot of this parity" (of my latest all-reduce of that parity)
+        hipEvent_t read_event[2] = {};
+        bool read_valid[2] = {false, false};
+    };
+    std::mutex m;
+    std::condition_variable cv;
+    int world = 0, alive = 0;
+    std::vector<Mail> mail;
+    float* d_slots = nullptr;  // [2][world][SLOT_FLOATS]: all-reduce contributions, double-buffered
+    static constexpr int SLOT_FLOATS = 64;
+
+    // rank posts `post` under the next tag and waits until every peer in [peer_lo, peer_hi] has posted
+    // that tag too; returns the tag
+    long post_and_wait(int rank, long tag, const Post& post, int peer_lo, int peer_hi)
+    {
+        std::unique_lock<std::mutex> lock(m);
+        Mail& mine = mail[rank];
+        const hipEvent_t keep = mine.ring[tag % RING].event;
+        mine.ring[tag % RING] = post;
+        if (!post.event) mine.ring[tag % RING].event = keep;
+        mine.tag = tag;
+        cv.notify_all();
+        cv.wait(lock, [&] {
+            for (int p = peer_lo; p <= peer_hi; p++)
+                if (p != rank && p >= 0 && p < world && mail[p].tag < tag) return false;
+            return true;
+        });
+        return tag;
+    }
+    Post peek(int peer, long tag)
+    {
+        std::lock_guard<std::mutex> lock(m);
+        return mail[peer].ring[tag % RING];
+    }
+    hipEvent_t event_for(int rank, long tag)  // this rank's reusable event of that slot of the ring
+    {
+        std::lock_guard<std::mutex> lock(m);
+        hipEvent_t& e = mail[rank].events[tag % RING];
+        if (!e) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        return e;
+    }
+};
+
+__global__ void k_loop_allreduce(float* __restrict__ buf, const float* __restrict__ slots, int world, int count,
+    int slot_floats)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count) return;
+    float sum = slots[k];  // rank 0, then the others in rank order: the same bits on every rank
+    for (int r = 1; r < world; r++) sum = sum + slots[(size_t)r * slot_floats + k];
+    buf[k] = sum;
+}
+
 struct ya_comm {
     int rank = 0, world = 1;
     ncclComm_t comm = nullptr;
     double* d_bounce = nullptr;  // 64 doubles for ya_comm_allreduce_host
+    Loop_group* loop = nullptr;  // a loopback communicator (ya_comm_create_loopback)
+    long phase = 0;              // loopback: phases posted so far
+    long allreduces = 0;         // loopback: all-reduces begun so far
 };
+
+namespace {
+int loop_exchange(ya_comm* c, const void* send_lo, size_t send_lo_bytes, void* recv_lo, size_t recv_lo_bytes,
+    const void* send_hi, size_t send_hi_bytes, void* recv_hi, size_t recv_hi_bytes, hipStream_t st)
+{
+    Loop_group& g = *c->loop;
+    const int lo = c->rank - 1, hi = c->rank + 1;
+    // phase A: "my send buffers are ready once my stream has got here"
+    Loop_group::Post mine;
+    mine.send_lo = send_lo;
+    mine.send_hi = send_hi;
+    mine.send_lo_bytes = send_lo_bytes;
+    mine.send_hi_bytes = send_hi_bytes;
+    const long tag_a = c->phase++;
+    mine.event = g.event_for(c->rank, tag_a);
+    if (hipEventRecord(mine.event, st) != hipSuccess) return 996;
+    g.post_and_wait(c->rank, tag_a, mine, lo, hi);
+    // the receives: behind the senders' streams, into my buffers, on my stream
+    if (lo >= 0 && recv_lo_bytes) {
+        const Loop_group::Post from = g.peek(lo, tag_a);
+        if (from.send_hi_bytes != recv_lo_bytes) return 995;  // the two ends disagree about a message's size
+        if (hipStreamWaitEvent(st, from.event, 0) != hipSuccess ||
+            hipMemcpyAsync(recv_lo, from.send_hi, recv_lo_bytes, hipMemcpyDeviceToDevice, st) != hipSuccess)
+            return 996;
+    }
+    if (hi < c->world && recv_hi_bytes) {
+        const Loop_group::Post from = g.peek(hi, tag_a);
+        if (from.send_lo_bytes != recv_hi_bytes) return 995;
+        if (hipStreamWaitEvent(st, from.event, 0) != hipSuccess ||
+            hipMemcpyAsync(recv_hi, from.send_lo, recv_hi_bytes, hipMemcpyDeviceToDevice, st) != hipSuccess)
+            return 996;
+    }
+    // phase B: "I have taken what you sent once my stream has got here" -- a send completes, in the
+    // sender's stream order, when its receiver has the data (the sender may then reuse the buffer)
+    Loop_group::Post taken;
+    const long tag_b = c->phase++;
+    taken.event = g.event_for(c->rank, tag_b);
+    if (hipEventRecord(taken.event, st) != hipSuccess) return 996;
+    g.post_and_wait(c->rank, tag_b, taken, lo, hi);
+    if (lo >= 0 && send_lo_bytes && hipStreamWaitEvent(st, g.peek(lo, tag_b).event, 0) != hipSuccess) return 996;
+    if (hi < c->world && send_hi_bytes && hipStreamWaitEvent(st, g.peek(hi, tag_b).event, 0) != hipSuccess) return 996;
+    return 0;
+}
+
+int loop_allreduce(ya_comm* c, float* d_buf, int count, hipStream_t st)
+{
+    Loop_group& g = *c->loop;
+    if (count > Loop_group::SLOT_FLOATS) return (int)hipErrorInvalidValue;
+    const int parity = (int)(c->allreduces++ & 1);
+    float* slots = g.d_slots + (size_t)parity * g.world * Loop_group::SLOT_FLOATS;
+    // My slot of this parity was read by everybody in the all-reduce before last: wait for those reads.
+    // (Every rank has queued them by now: it passed the last all-reduce's rendezvous after that.)
+    for (int p = 0; p < g.world; p++) {
+        hipEvent_t e = nullptr;
+        {
+            std::lock_guard<std::mutex> lock(g.m);
+            if (g.mail[p].read_valid[parity]) e = g.mail[p].read_event[parity];
+        }
+        if (p != c->rank && e && hipStreamWaitEvent(st, e, 0) != hipSuccess) return 996;
+    }
+    if (hipMemcpyAsync(slots + (size_t)c->rank * Loop_group::SLOT_FLOATS, d_buf, (size_t)count * sizeof(float),
+            hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return 996;
+    Loop_group::Post mine;
+    const long tag = c->phase++;
+    mine.event = g.event_for(c->rank, tag);
+    if (hipEventRecord(mine.event, st) != hipSuccess) return 996;
+    g.post_and_wait(c->rank, tag, mine, 0, g.world - 1);
+    for (int p = 0; p < g.world; p++)
+        if (p != c->rank && hipStreamWaitEvent(st, g.peek(p, tag).event, 0) != hipSuccess) return 996;
+    k_loop_allreduce<<<1, 64, 0, st>>>(d_buf, slots, g.world, count, Loop_group::SLOT_FLOATS);
+    {
+        std::lock_guard<std::mutex> lock(g.m);
+        Loop_group::Mail& me = g.mail[c->rank];
+        if (!me.read_event[parity]) (void)hipEventCreateWithFlags(&me.read_event[parity], hipEventDisableTiming);
+        if (hipEventRecord(me.read_event[parity], st) != hipSuccess) return 996;
+        me.read_valid[parity] = true;
+    }
+    return 0;
+}
+}  // namespace
 
 extern "C" {
 
@@ -296,9 +459,50 @@ int ya_comm_create_from_env(int port_offset, ya_comm** out)
     return ya_comm_create(id, rank, world, out);
 }
 
+int ya_comm_create_loopback(int world, ya_comm** out)
+{
+    if (!out || world < 1 || world > 64) return (int)hipErrorInvalidValue;
+    Loop_group* g = new Loop_group;
+    g->world = g->alive = world;
+    g->mail.resize(world);
+    if (hipMalloc(&g->d_slots, 2 * (size_t)world * Loop_group::SLOT_FLOATS * sizeof(float)) != hipSuccess) {
+        delete g;
+        return (int)hipErrorOutOfMemory;
+    }
+    for (int r = 0; r < world; r++) {
+        ya_comm* c = new ya_comm;
+        c->rank = r;
+        c->world = world;
+        c->loop = g;
+        out[r] = c;
+    }
+    return 0;
+}
+
 int ya_comm_destroy(ya_comm* c)
 {
     if (!c) return 0;
+    if (c->loop) {
+        Loop_group* g = c->loop;
+        bool last;
+        {
+            std::lock_guard<std::mutex> lock(g->m);
+            last = --g->alive == 0;
+        }
+        if (last) {
+            (void)hipDeviceSynchronize();
+            for (auto& mail : g->mail) {
+                for (hipEvent_t e : mail.events)
+                    if (e) (void)hipEventDestroy(e);
+                for (hipEvent_t e : mail.read_event)
+                    if (e) (void)hipEventDestroy(e);
+            }
+            (void)hipFree(g->d_slots);
+            delete g;
+        }
+        delete c;
+        return 0;
+    }
     if (c->comm) {
         Rccl* r = rccl();
         if (r) (void)r->CommDestroy(c->comm);
@@ -316,6 +520,11 @@ int ya_comm_exchange(ya_comm* c, const void* d_send_lo, void* d_recv_lo, const v
 {
     if (!c) return (int)hipErrorInvalidValue;
     if (c->world == 1 || bytes == 0) return 0;
+    if (c->loop) {
+        const bool has_lo = c->rank > 0, has_hi = c->rank + 1 < c->world;
+        return loop_exchange(c, d_send_lo, has_lo ? bytes : 0, d_recv_lo, has_lo ? bytes : 0, d_send_hi, has_hi ? bytes : 0,
+            d_recv_hi, has_hi ? bytes : 0, (hipStream_t)stream);
+    }
     Rccl* r = rccl();
     if (!r) return 999;
     hipStream_t st = (hipStream_t)stream;
@@ -341,6 +550,10 @@ int ya_comm_exchange_v(ya_comm* c, const void* d_send_lo, size_t send_lo_bytes, 
 {
     if (!c) return (int)hipErrorInvalidValue;
     if (c->world == 1) return 0;
+    if (c->loop)
+        return loop_exchange(c, d_send_lo, c->rank > 0 ? send_lo_bytes : 0, d_recv_lo, c->rank > 0 ? recv_lo_bytes : 0,
+            d_send_hi, c->rank + 1 < c->world ? send_hi_bytes : 0, d_recv_hi, c->rank + 1 < c->world ? recv_hi_bytes : 0,
+            (hipStream_t)stream);
     Rccl* r = rccl();
     if (!r) return 999;
     hipStream_t st = (hipStream_t)stream;
@@ -377,6 +590,7 @@ int ya_comm_self_exchange(ya_comm* c, const void* d_send, void* d_recv, size_t b
 int ya_comm_allreduce_sum(ya_comm* c, float* d_buf, int count, void* stream)
 {
     if (!c || !d_buf || count < 0) return (int)hipErrorInvalidValue;
+    if (c->loop) return c->world == 1 || count == 0 ? 0 : loop_allreduce(c, d_buf, count, (hipStream_t)stream);
     if (!c->comm || count == 0) return 0;
     Rccl* r = rccl();
     if (!r) return 999;
@@ -388,6 +602,26 @@ int ya_comm_allreduce_sum(ya_comm* c, float* d_buf, int count, void* stream)
 int ya_comm_allreduce_host(ya_comm* c, double* values, int count, int take_max)
 {
     if (!c || !values || count < 0 || count > 64) return (int)hipErrorInvalidValue;
+    if (c->loop) {  // host values: through the rendezvous itself
+        if (c->world == 1 || count == 0) return 0;
+        Loop_group& g = *c->loop;
+        Loop_group::Post mine;
+        for (int k = 0; k < count; k++) mine.host_values[k] = values[k];
+        const long tag = c->phase++;
+        g.post_and_wait(c->rank, tag, mine, 0, g.world - 1);
+        for (int k = 0; k < count; k++) {
+            double acc = g.peek(0, tag).host_values[k];
+            for (int p = 1; p < g.world; p++) {
+                const double v = g.peek(p, tag).host_values[k];
+                acc = take_max ? (v > acc ? v : acc) : acc + v;
+            }
+            values[k] = acc;
+        }
+        // (nobody's post of this tag is overwritten before everybody has read it: the ring holds 8 phases
+        // and the next operation's rendezvous comes first)
+        g.post_and_wait(c->rank, c->phase++, Loop_group::Post{}, 0, g.world - 1);
+        return 0;
+    }
     if (!c->comm || count == 0) return 0;
     Rccl* r = rccl();
     if (!r) return 999;

@@ -143,6 +143,21 @@ class NativeComm:
             self.handle = None
 
 
+def loopback_comms(world):
+    """`world` NativeComm handles for the slabs of THIS process on one GPU (ya_comm_create_loopback):
+    stream-ordered device-to-device messages and a kernel all-reduce behind the RCCL entry points, so that
+    the decomposed step's asynchronous path (the exchange on its own stream beside the interior launch)
+    runs against real peers where RCCL cannot (it refuses two ranks on one GPU).  One host thread per
+    handle (run_slabs(..., comms=...)); close() every one."""
+    lib = NativeComm._bind()
+    lib.ya_comm_create_loopback.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    handles = (C.c_void_p * world)()
+    code = lib.ya_comm_create_loopback(int(world), handles)
+    if code != 0:
+        raise YallaError(f"ya_comm_create_loopback failed ({code})")
+    return [NativeComm(_handle=C.c_void_p(h)) for h in handles]
+
+
 class _Memory:
     """Reading / writing the raw buffers the engine hands to a transport callback: host memory
     on the oracle, device memory on the HIP engine (blocking copies through libyalla_hip.so)."""
@@ -434,14 +449,18 @@ class Slab:
         self.sim.close()
 
 
-def run_slabs(slabs, dt, steps, migrate_every=1, device_memory=False):
+def run_slabs(slabs, dt, steps, migrate_every=1, device_memory=False, comms=None):
     """`steps` take_steps of all slabs of one system inside this process: a host thread per slab
-    runs the native step (ya_slab_step) with a ThreadTransport.  Migration every
-    `migrate_every`-th step and after the last one."""
+    runs the native step (ya_slab_step) with a ThreadTransport -- or, with `comms` (loopback_comms), with
+    the communicators' stream-ordered transport, i.e. through the step's asynchronous path.  Migration
+    every `migrate_every`-th step and after the last one."""
     world = len(slabs)
     shared = ThreadTransport.Shared(world, device_memory)
     for r, s in enumerate(slabs):
-        s.use(transport=ThreadTransport(shared, r))
+        if comms is not None:
+            s.use(comm=comms[r])
+        else:
+            s.use(transport=ThreadTransport(shared, r))
     errors = []
 
     def work(s):
