@@ -53,11 +53,6 @@ struct Slab_device_ops {
     {
         YA_CHECK(ya_select_z(X, stride, n, z_min, z_max, idx, count, ws, nullptr));
     }
-    static void gather_rows(const void* src, size_t row_bytes, const int* idx, const int* count, int cap,
-        void* dst)
-    {
-        YA_CHECK(ya_gather_rows(src, row_bytes, idx, count, cap, dst, nullptr));
-    }
     static void gather_rows_pair(const void* src, size_t row_bytes, const int* idx0, const int* count0, void* dst0,
         const int* idx1, const int* count1, void* dst1, int cap)
     {
@@ -72,14 +67,6 @@ struct Slab_device_ops {
         int v;
         YA_CHECK(ya_memcpy_d2h(&v, d, sizeof(int)));
         return v;
-    }
-    static void append_rows(void* dst, size_t row_bytes, int n_own, const void* lo, const void* hi, int cap,
-        size_t payload_offset, int* n_out)
-    {
-        // a message = 16-byte header {int count}, then the rows
-        YA_CHECK(ya_append_rows(dst, row_bytes, n_own, lo ? (const char*)lo + payload_offset : nullptr,
-            (const int*)lo, hi ? (const char*)hi + payload_offset : nullptr, (const int*)hi, cap, n_out,
-            nullptr));
     }
     static void pack_cells(void* const arrays[3], const size_t row_bytes[3], const int* idx, const int* count, int cap,
         void* message, size_t header)

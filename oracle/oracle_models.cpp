@@ -54,19 +54,6 @@ struct Oracle_slab_ops {
 }
     static void copy(void* dst, const void* src, size_t bytes) { memmove(dst, src, bytes); }
     static int read_int(const void* d) { return *(const int*)d; }
-    static void append_rows(void* dst, size_t row_bytes, int n_own, const void* lo, const void* hi,
-    int cap, size_t payload_offset, int* n_out)
-{
-    int n = n_own;
-    for (const void* m : {lo, hi}) {
-        if (!m) continue;
-        int c = *(const int*)m;
-        c = c < 0 ? 0 : (c > cap ? cap : c);
-        memcpy((char*)dst + (size_t)n * row_bytes, (const char*)m + payload_offset, (size_t)c * row_bytes);
-        n += c;
-    }
-    if (n_out) *n_out = n;
-}
 // a cell's record -- three arrays with their own row widths -- moved together (ya_pack_cells,
 // ya_append_cells, ya_fill_holes of include/yalla_hip.h, restated serially)
     static void pack_cells(void* const arrays[3], const size_t row_bytes[3], const int* idx, const int* count, int cap,
