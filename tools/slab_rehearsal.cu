@@ -45,6 +45,9 @@ __device__ float3 spring(float3 Xi, float3 r, float dist, int i, int j)  // exam
 // (tools/slab_trace_summary.py: device-busy time per slab and step).
 template<int RANK>
 __global__ void slab_takes_the_gpu() {}
+// ... and one when it hands the GPU back: what follows until the next slab's marker is the REHEARSAL's
+// transport (messages as device-to-device copies, the all-reduce through the host), not the slab's work
+__global__ void slab_hands_the_gpu_back() {}
 static void mark(int rank)
 {
     switch (rank & 7) {
@@ -148,6 +151,10 @@ struct Rank {
             per_step[segment][step_index] += span;
         }
         segment++;
+        if (shared->markers) {
+            slab_hands_the_gpu_back<<<1, 1>>>();
+            (void)hipDeviceSynchronize();
+        }
         if (shared->rotate) {
             {
                 std::lock_guard<std::mutex> lock(shared->gpu);

@@ -43,10 +43,15 @@ def main(path, steps, skip=0):
         if m:
             rank = int(m.group(1))
             continue
+        if "slab_hands_the_gpu_back" in name:
+            rank = "transport"   # the rehearsal's own copies between the slabs' buffers: nobody's work
+            continue
         per_rank[rank].append((a, b, name))
     out = {"undivided_device_ms_per_step": union([(a, b) for a, b, _ in whole]) / n_whole_steps / 1e6,
            "undivided_steps": n_whole_steps, "slabs": []}
     worst = worst_kernels = 0
+    transport = per_rank.pop("transport", [])
+    out["rehearsal_transport_ms_per_step_all_slabs"] = sum(b - a for a, b, _ in transport) / steps / 1e6
     for r in sorted(per_rank):
         ks = per_rank[r]
         busy = union([(a, b) for a, b, _ in ks]) / steps / 1e6
@@ -85,8 +90,9 @@ def main(path, steps, skip=0):
     # (SLAB_TIMELINE_RANK=r: one stretch of that slab's launches -- start, duration, kernel -- on stderr)
     import os
     if os.environ.get("SLAB_TIMELINE_RANK"):
+        per_rank["transport"] = transport
         for which in os.environ["SLAB_TIMELINE_RANK"].split(","):
-            ks = per_rank[int(which)]
+            ks = per_rank[which if which == "transport" else int(which)]
             lo = len(ks) // 2
             print(f"---- rank {which}", file=sys.stderr)
             for a, b, n in ks[lo:lo + 140]:
@@ -96,7 +102,10 @@ def main(path, steps, skip=0):
     out["slowest_slab_device_ms_per_step_without_copies"] = worst_kernels
     out["projected_speedup_device_time_only_without_copies"] = out["undivided_device_ms_per_step"] / worst_kernels
     out["note"] = ("device-busy time only (no host launch gaps, no RCCL latency, no xGMI transfer time; the rehearsal's "
-                   "own copies between slabs are attributed to no slab): the optimistic bracket of the projection")
+                   "own copies between the slabs' buffers -- its stand-in for RCCL -- run after the marker "
+                   "slab_hands_the_gpu_back and are attributed to no slab; a slab's own copy kernels, a few per "
+                   "selection of the mirrored cells, are in its device time and listed under copy_fill): the "
+                   "optimistic bracket of the projection")
     print(json.dumps(out, indent=1))
 
 
