@@ -656,9 +656,9 @@ namespace ya {
 // stretch.  A workgroup is ONE wavefront (64 cells): nothing waits at a workgroup barrier
 // for a slower wavefront, launches of 10^4..10^5 cells spread over four times as many
 // CUs, and the workgroup needs 7 KiB of LDS.  MI355X, same box (tools/micro/force_ab.hip):
-// 242 us per 1 M-cell launch against 260 us for grid_force, 62 against 75 us at 10^5 cells,
+// 242 us per 1 M-cell launch against 260 us for round 1's byte-FIFO kernel, 62 against 75 us at 10^5 cells,
 // 803 against 853 us at 4 M.  What bounds it is the VALU issue rate.
-// Results are bit-identical to grid_force / grid_force_direct: same candidates, same
+// Results are bit-identical to the earlier kernels' (include/experimental/force_variants.cuh): same candidates, same
 // order, same arithmetic.
 // The friction terms of one pair (solvers.cuh:309-313, :453-458): sum_friction += friction,
 // sum_v += friction * old_v[j].  For the default functor friction_w_neighbour the coefficient
@@ -1009,7 +1009,8 @@ __global__ __launch_bounds__(bits::BLOCK, (bits::Min_waves<Pt, LOCAL_IDS>::value
 }
 
 // ---------------------------------------------------------------------------------
-// grid_force_coop (opt-in, Grid_computer::force_variant = 3): the grid force with SEVERAL LANES
+// grid_force_coop (the solver's own choice below ~1.5 * 10^5 cells for functors declared YA_STATELESS;
+// forced by Grid_computer::force_variant = 3): the grid force with SEVERAL LANES
 // PER CELL, for systems too small to fill the chip with one lane per cell.  A launch of
 // <= 10^5 cells is at most one wavefront per SIMD for the kernels above, each lane working
 // through its ~265 candidates and ~41 hits alone: 52-65 us whatever n is.  Here a 256-thread
@@ -2320,7 +2321,8 @@ class Grid_computer {
 public:
     float cube_size;
     ya::Profiler profiler;
-    // 2 = grid_force_bits (bit stream) always, 1 = grid_force (byte FIFO), 0 = grid_force_direct (A/B);
+    // 2 = grid_force_bits (bit stream) always; 1 = grid_force (byte FIFO), 0 = grid_force_direct: the A/B
+    // baselines of include/experimental/force_variants.cuh, only with -DYA_EXPERIMENTAL_FORCE_VARIANTS;
     // 3 = grid_force_coop below ~1.5 * 10^5 cells (16, 8 or 4 lanes per cell, more the smaller the
     // system), grid_force_bits above: for models whose functors keep no per-cell state without
     // atomics (bit-identical results; see the kernel's comment)
