@@ -277,6 +277,7 @@ int main(int argc, char** argv)
         ranks[r].rank = r;
         s.slab_set_transport(exchange_cb, allreduce_cb, &ranks[r]);
         s.migrate_every = migrate_every;
+        if (const char* v = getenv("YALLA_SLAB_LOCAL_ORDER")) s.slab.local_order_every = atoi(v);  // A/B: 0 = never
     }
     X0.clear();
     X0.shrink_to_fit();
