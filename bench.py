@@ -211,6 +211,8 @@ def counters_key(args, n_total):
     if args.model == "sorting_grid" and n_total == 10_000:
         return "cfg2_sorting_10k" + tier
     renumbered = "_renumbered" if args.renumber_every > 0 else ""
+    if renumbered and args.model not in STATE_MODELS:
+        return None
     if args.model == "branching_grid":
         return "cfg3_branching_100k" + renumbered + tier
     if args.model == "passive_growth_grid":
@@ -462,9 +464,9 @@ def main(argv=None):
         if args.model.startswith("sorting"):
             sim.set_param("n_cells", n_total)
         if args.renumber_every > 0:
-            if args.model not in STATE_MODELS:
-                sys.exit("bench.py: --renumber-every is for the models that index per-cell arrays by id "
-                         "(passive_growth_grid, branching_grid)")
+            if args.model not in STATE_MODELS and args.model not in ("springs_grid", "clipped_grid", "relu_grid"):
+                sys.exit("bench.py: --renumber-every is for the models whose harness hands every id-indexed array "
+                         "over (passive_growth_grid, branching_grid) or that have none (springs_grid, clipped_grid, relu_grid)")
             sim.set_param("renumber_now", 1)
             sim.set_param("renumber_every", args.renumber_every)
         if args.model.endswith("_tile") and args.tile_lanes != 1:
