@@ -21,6 +21,7 @@
 #include <sys/socket.h>
 #include <unistd.h>
 
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <string>
@@ -189,7 +190,8 @@ struct Loop_group {
     static constexpr int SLOT_FLOATS = 64;
 
     // rank posts `post` under the next tag and waits until every peer in [peer_lo, peer_hi] has posted
-    // that tag too; returns the tag
+    // that tag too; returns the tag, or -1 if a peer has not shown up within ten minutes (its thread died:
+    // a test must fail, not hang)
     long post_and_wait(int rank, long tag, const Post& post, int peer_lo, int peer_hi)
     {
         std::unique_lock<std::mutex> lock(m);
@@ -199,12 +201,12 @@ struct Loop_group {
         if (!post.event) mine.ring[tag % RING].event = keep;
         mine.tag = tag;
         cv.notify_all();
-        cv.wait(lock, [&] {
+        const bool met = cv.wait_for(lock, std::chrono::minutes(10), [&] {
             for (int p = peer_lo; p <= peer_hi; p++)
                 if (p != rank && p >= 0 && p < world && mail[p].tag < tag) return false;
             return true;
         });
-        return tag;
+        return met ? tag : -1;
     }
     Post peek(int peer, long tag)
     {
@@ -254,7 +256,7 @@ int loop_exchange(ya_comm* c, const void* send_lo, size_t send_lo_bytes, void* r
     const long tag_a = c->phase++;
     mine.event = g.event_for(c->rank, tag_a);
     if (hipEventRecord(mine.event, st) != hipSuccess) return 996;
-    g.post_and_wait(c->rank, tag_a, mine, lo, hi);
+    if (g.post_and_wait(c->rank, tag_a, mine, lo, hi) < 0) return 994;
     // the receives: behind the senders' streams, into my buffers, on my stream
     if (lo >= 0 && recv_lo_bytes) {
         const Loop_group::Post from = g.peek(lo, tag_a);
@@ -276,7 +278,7 @@ int loop_exchange(ya_comm* c, const void* send_lo, size_t send_lo_bytes, void* r
     const long tag_b = c->phase++;
     taken.event = g.event_for(c->rank, tag_b);
     if (hipEventRecord(taken.event, st) != hipSuccess) return 996;
-    g.post_and_wait(c->rank, tag_b, taken, lo, hi);
+    if (g.post_and_wait(c->rank, tag_b, taken, lo, hi) < 0) return 994;
     if (lo >= 0 && send_lo_bytes && hipStreamWaitEvent(st, g.peek(lo, tag_b).event, 0) != hipSuccess) return 996;
     if (hi < c->world && send_hi_bytes && hipStreamWaitEvent(st, g.peek(hi, tag_b).event, 0) != hipSuccess) return 996;
     return 0;
@@ -305,7 +307,7 @@ int loop_allreduce(ya_comm* c, float* d_buf, int count, hipStream_t st)
     const long tag = c->phase++;
     mine.event = g.event_for(c->rank, tag);
     if (hipEventRecord(mine.event, st) != hipSuccess) return 996;
-    g.post_and_wait(c->rank, tag, mine, 0, g.world - 1);
+    if (g.post_and_wait(c->rank, tag, mine, 0, g.world - 1) < 0) return 994;
     for (int p = 0; p < g.world; p++)
         if (p != c->rank && hipStreamWaitEvent(st, g.peek(p, tag).event, 0) != hipSuccess) return 996;
     k_loop_allreduce<<<1, 64, 0, st>>>(d_buf, slots, g.world, count, Loop_group::SLOT_FLOATS);
@@ -608,7 +610,7 @@ int ya_comm_allreduce_host(ya_comm* c, double* values, int count, int take_max)
         Loop_group::Post mine;
         for (int k = 0; k < count; k++) mine.host_values[k] = values[k];
         const long tag = c->phase++;
-        g.post_and_wait(c->rank, tag, mine, 0, g.world - 1);
+        if (g.post_and_wait(c->rank, tag, mine, 0, g.world - 1) < 0) return 994;
         for (int k = 0; k < count; k++) {
             double acc = g.peek(0, tag).host_values[k];
             for (int p = 1; p < g.world; p++) {
@@ -619,8 +621,7 @@ int ya_comm_allreduce_host(ya_comm* c, double* values, int count, int take_max)
         }
         // (nobody's post of this tag is overwritten before everybody has read it: the ring holds 8 phases
         // and the next operation's rendezvous comes first)
-        g.post_and_wait(c->rank, c->phase++, Loop_group::Post{}, 0, g.world - 1);
-        return 0;
+        return g.post_and_wait(c->rank, c->phase++, Loop_group::Post{}, 0, g.world - 1) < 0 ? 994 : 0;
     }
     if (!c->comm || count == 0) return 0;
     Rccl* r = rccl();
