@@ -611,6 +611,14 @@ inline float cutoff_squared(float cube_size)
     return t;
 }
 
+// A model's pairwise functor is inlined where the grid kernels call it, whatever its size.  Left to
+// the inliner, a functor with libm calls in it (bending_force's sinf / cosf) stays a function that is
+// called per pair: it then re-reads the device symbols it uses (`d_type`, `d_mes_nbs` ...) and cell i's
+// own entries for every pair, each of them a round trip in front of the arithmetic.
+#ifndef YA_CALL_INLINED
+#define YA_CALL_INLINED [[clang::always_inline]]
+#endif
+
 // Row bounds of a plane of the stencil for a workgroup that owns the cubes [c_lo, c_hi] and a lane in
 // cube c: six workgroup-uniform and six per-lane reads of offs[].  Those of plane p + 1 are requested
 // while plane p computes, so that a plane's staging loads do not queue behind a round trip to L2 for
@@ -713,26 +721,22 @@ namespace bits {
 // functor's own global accesses (d_type[i], d_type[j], d_mes_nbs[i] += 1 by original id: 64 cache
 // lines per wavefront instruction, TA 73 % busy), and more wavefronts only queue there.
 // Round 4: once the MODEL keeps its ids in cube order (Solution::renumber) those accesses are
-// neighbouring lines and the picture turns round -- four wavefronts per SIMD and one hit per trip
-// are then the faster build, 652 -> 585 us per launch (profiles/r04_cfg4_renumber_ab.txt).  The
-// solver launches that build (LOCAL_IDS) for wide points after a renumbering and the reference-
-// semantics build otherwise; both are the same kernel source.
+// neighbouring lines, and while the functor was still a called function four wavefronts per SIMD and
+// one hit per trip were the faster build there, 652 -> 585 us per launch (profiles/r04_cfg4_renumber_ab.txt:
+// a second build of the kernel for renumbered models).  With the functor inlined (YA_CALL_INLINED) the
+// compiler's own choice and two hits per trip are the fastest again, renumbered or not: 559-566 us
+// (profiles/r04_inline_ab.txt) -- a four-wavefront build then spills the force sums inside the loop
+// (752 us; 1000 us with `int* d_type`) -- and the second build is gone.
 #ifndef YA_BITS_MIN_WAVES_WIDE
 #define YA_BITS_MIN_WAVES_WIDE 1
 #endif
-#ifndef YA_BITS_MIN_WAVES_WIDE_LOCAL
-#define YA_BITS_MIN_WAVES_WIDE_LOCAL 4
-#endif
-#ifndef YA_BITS_POPS_WIDE_LOCAL
-#define YA_BITS_POPS_WIDE_LOCAL 1
-#endif
-template<typename Pt, bool LOCAL_IDS = false>
+template<typename Pt>
 struct Min_waves {
-    static constexpr int value = sizeof(Pt) <= 16 ? 1 : (LOCAL_IDS ? YA_BITS_MIN_WAVES_WIDE_LOCAL : YA_BITS_MIN_WAVES_WIDE);
+    static constexpr int value = sizeof(Pt) <= 16 ? 1 : YA_BITS_MIN_WAVES_WIDE;
 };
-template<typename Pt, bool LOCAL_IDS = false>
+template<typename Pt>
 struct Pops {
-    static constexpr int value = sizeof(Pt) <= 16 ? YA_BITS_POPS : (LOCAL_IDS ? YA_BITS_POPS_WIDE_LOCAL : YA_BITS_POPS_WIDE);
+    static constexpr int value = sizeof(Pt) <= 16 ? YA_BITS_POPS : YA_BITS_POPS_WIDE;
 };
 constexpr int BLOCK = YA_BITS_BLOCK;
 constexpr int WORDS = YA_MASK_WORDS;
@@ -763,8 +767,7 @@ __device__ __forceinline__ void shift_in(unsigned& m, const float d2, const floa
 // One pass: up to three candidate segments [b_r, e_r) of the staged cells (LDS indices;
 // empty if b_r >= e_r), at most PASS_BITS bits after padding each to a multiple of four.
 // shift_r turns an LDS index of segment r into a slot of the sorted arrays.
-template<typename Pt, Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction, bool STAGE_V, bool GLOBAL_IDS,
-    bool LOCAL_IDS = false>
+template<typename Pt, Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction, bool STAGE_V, bool GLOBAL_IDS>
 __device__ __forceinline__ void pass(const Entry<Pt>* __restrict__ sh_e, const float4* __restrict__ sh_v,
     Lds_word* const words,
     const int b0, const int e0, const int b1, const int e1, const int b2, const int e2,
@@ -772,7 +775,7 @@ __device__ __forceinline__ void pass(const Entry<Pt>* __restrict__ sh_e, const f
     const Pt& Xi, const int i, const float cut2, Pt& F, float3& sum_v, float& sum_friction,
     const int* __restrict__ global_id)
 {
-    constexpr int POPS = Pops<Pt, LOCAL_IDS>::value;
+    constexpr int POPS = Pops<Pt>::value;
     // ---- phase 1 ----
     unsigned m = 0;
     int p = 0;  // bits emitted
@@ -832,7 +835,7 @@ __device__ __forceinline__ void pass(const Entry<Pt>* __restrict__ sh_e, const f
         Pt r = Xi - other_.X;                                                          \
         float dist = dist3(r.x, r.y, r.z);                                             \
         const int j = GLOBAL_IDS ? global_id[other_.id] : other_.id;                   \
-        F += pw_int(Xi, r, dist, i, j);                                                \
+        YA_CALL_INLINED F += pw_int(Xi, r, dist, i, j);                                \
         pair_friction<Pt, pw_friction>(Xi, r, dist, i, j, v_, sum_v, sum_friction);    \
     }
     while (cur != 0 || left > 0) {
@@ -869,10 +872,9 @@ __device__ __forceinline__ void pass(const Entry<Pt>* __restrict__ sh_e, const f
 
 // GLOBAL_IDS (z-slab decomposition): functors get global_id[local index]; a template parameter
 // rather than a null test so that the single-GPU kernel carries neither the test nor the gather.
-// LOCAL_IDS (wide points only): the build for a model that keeps its ids in cube order, see bits::Min_waves.
 template<typename Pt, Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction, bool STAGE_V = false,
-    bool GLOBAL_IDS = false, bool LOCAL_IDS = false>
-__global__ __launch_bounds__(bits::BLOCK, (bits::Min_waves<Pt, LOCAL_IDS>::value)) void grid_force_bits(const int n,
+    bool GLOBAL_IDS = false>
+__global__ __launch_bounds__(bits::BLOCK, bits::Min_waves<Pt>::value) void grid_force_bits(const int n,
     const Entry<Pt>* __restrict__ sorted, const float4* __restrict__ sorted_v,
     const int* __restrict__ cube_id, const int* __restrict__ offs, const int gs,
     const int n_cubes, const float cut2, Pt* __restrict__ d_dX, const bool has_gen,
@@ -983,7 +985,7 @@ __global__ __launch_bounds__(bits::BLOCK, (bits::Min_waves<Pt, LOCAL_IDS>::value
             const int bits_needed = (max(se[0] - sb[0], 0) + 3 & ~3) + (max(se[1] - sb[1], 0) + 3 & ~3) +
                                     (max(se[2] - sb[2], 0) + 3 & ~3);
             if (!__any(bits_needed > bits::PASS_BITS)) {
-                bits::pass<Pt, pw_int, pw_friction, STAGE_V, GLOBAL_IDS, LOCAL_IDS>(sh_e, sh_v, words, sb[0], se[0], sb[1], se[1], sb[2],
+                bits::pass<Pt, pw_int, pw_friction, STAGE_V, GLOBAL_IDS>(sh_e, sh_v, words, sb[0], se[0], sb[1], se[1], sb[2],
                     se[2], shift[0], shift[1], shift[2], sorted_v, Xi, gi, cut2, F, sum_v, sum_friction,
                     global_id);
             } else {
@@ -995,7 +997,7 @@ __global__ __launch_bounds__(bits::BLOCK, (bits::Min_waves<Pt, LOCAL_IDS>::value
                     const int rs = r == 0 ? shift[0] : (r == 1 ? shift[1] : shift[2]);
 #pragma unroll 1
                     for (int b = rb; __any(b < re); b += bits::PASS_BITS)
-                        bits::pass<Pt, pw_int, pw_friction, STAGE_V, GLOBAL_IDS, LOCAL_IDS>(sh_e, sh_v, words, b, min(re, b + bits::PASS_BITS),
+                        bits::pass<Pt, pw_int, pw_friction, STAGE_V, GLOBAL_IDS>(sh_e, sh_v, words, b, min(re, b + bits::PASS_BITS),
                             0, 0, 0, 0, rs, 0, 0, sorted_v, Xi, gi, cut2, F, sum_v, sum_friction, global_id);
                 }
             }
@@ -1243,7 +1245,7 @@ __global__ __launch_bounds__(coop::BLOCK) void grid_force_coop(const int n,
                         Pt rr = Xi - other.X;
                         float dist = dist3(rr.x, rr.y, rr.z);
                         const int j = global_id ? global_id[other.id] : other.id;
-                        f = pw_int(Xi, rr, dist, gi, j);
+                        YA_CALL_INLINED f = pw_int(Xi, rr, dist, gi, j);
                         friction = pw_friction(Xi, rr, dist, gi, j);
                     }
 #pragma unroll
@@ -2508,13 +2510,6 @@ protected:
                 }
             } else if (stage_v) {
                 YA_BITS_LAUNCH(true, false);
-            } else if (sizeof(Pt) > 16 && ids_in_cube_order) {
-                // the model renumbers its cells (Solution::renumber): the build with more wavefronts per SIMD
-                YA_FORCE_LAUNCH((ya::grid_force_bits<Pt, pw_int, pw_friction, false, false, (sizeof(Pt) > 16)>),
-                    (n + ya::bits::BLOCK - 1) / ya::bits::BLOCK, ya::bits::BLOCK, n, d_cells, d_cells_v,
-                    (const int*)grid.d_cube_id, grid.offsets(), grid.grid_size, grid.n_cubes, cut2, d_dX, has_gen, n_active,
-                    d_dX_in_cell_order, (const int*)d_global_id, part, force_part_cube_lo, force_part_cube_hi,
-                    force_own_cube_lo, force_own_cube_hi);
             } else {
                 YA_BITS_LAUNCH(false, false);
             }
@@ -2546,14 +2541,8 @@ protected:
         grid.build(n, d_X, cube_size);
         return grid.d_point_id;
     }
-    // ... after which cell s IS slot s: the next build visits the cells in storage order, and the
-    // force launches of wide points go to the build made for ids in cube order (bits::Min_waves)
-    void ids_changed()
-    {
-        grid.forget_order();
-        ids_in_cube_order = true;
-    }
-    bool ids_in_cube_order = false;
+    // ... after which cell s IS slot s: the next build visits the cells in storage order
+    void ids_changed() { grid.forget_order(); }
     // The part of the first stage's grid build that can be queued before the host knows
     // n (Heun_solver::take_step); pwints then only finishes the build.
     void begin_build(const Pt* d_X, const int* d_n, const int n_bound)

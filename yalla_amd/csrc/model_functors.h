@@ -124,7 +124,11 @@ __device__ inline void custom_force(
 // kept; its cuRAND draws are replaced by a counter-based hash so that the CPU
 // oracle and the GPU make the same proliferation decisions. -----------------------
 enum Cell_types { mesenchyme, epithelium };
+#ifdef YA_AB_TYPE_AS_INT
 YA_MODEL_VAR int* d_type;
+#else
+YA_MODEL_VAR Cell_types* d_type;  // (an enumeration, as in passive_growth.cu:26: loads of it do not alias the counters' stores)
+#endif
 YA_MODEL_VAR int* d_mes_nbs;  // number of mesenchymal neighbours
 YA_MODEL_VAR int* d_epi_nbs;
 
