@@ -7,8 +7,14 @@ COM sum is reassociated across slabs (1e-7 relative per step), and the spring fo
 benchmark model is cut off at cube_size where it is NOT zero: a pair within rounding of the
 cut-off interacts in one run and not in the other, which moves two cells by 0.5 dt at once
 (about two such pairs per step per 40 000 cells) -- those cells are counted, not tolerated
-silently.  Slabs thinner than the ghost layer (tiny systems in many slabs) are skipped: a
-cell's neighbours would sit two slabs away."""
+silently, against a budget that follows that rate: four cells per step per 40 000 cells (a pair's
+two cells; two steps later their neighbours follow at 1e-4 through friction_w_neighbour, which
+averages the neighbours' velocities: seed 90007, 12 steps of 28 005 cells, 4 pairs and 11 of their
+neighbours, looked at step by step with tools/diag/slab_case.py -- the first cell differs after step
+10, none of the pairs sits nearer a cut than elsewhere).  A decomposition that loses cells'
+neighbours is off for every cell along a cut at once, hundreds of cells in the first step.  Slabs
+thinner than the ghost layer (tiny systems in many slabs) are skipped: a cell's neighbours would
+sit two slabs away."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -38,7 +44,7 @@ if __name__ == "__main__":
         diff = np.abs(X - Xref).max(axis=1)
         scale = np.abs(Xref).max()
         off = int((diff > 1e-5 * scale).sum())
-        ok = off <= max(4, n // 2000) and diff.max() <= 2.0 * steps * dt
+        ok = off <= max(4, n // 2000, int(4 * steps * n / 40000)) and diff.max() <= 2.0 * steps * dt
         bad += not ok
         print("ok  " if ok else "FAIL", case, "moved", moved, "cells beyond 1e-5:", off,
               "max diff %.2e" % diff.max(), flush=True)
