@@ -2,7 +2,9 @@
 """Randomised check of the z-slab decomposition on the device (test infrastructure; run on a GPU
 box: python tests/fuzz_slab.py [cases] [first_seed]): W slabs of one system on one GPU
 (LocalComm) against the undivided system; system size, slab count, step, step count and
-migration interval are drawn.  Criterion: 1e-5 relative for all but a handful of cells.  The
+migration interval are drawn.  Criterion for the benchmark's springs: 1e-5 relative for all but a handful
+of cells; for every third case, which runs fading_grid (a force that fades to zero at the cut-off,
+friction_on_background: yalla_amd/csrc/model_functors.h) over three times the steps: 2e-6 for EVERY cell.  The
 COM sum is reassociated across slabs (1e-7 relative per step), and the spring force of the
 benchmark model is cut off at cube_size where it is NOT zero: a pair within rounding of the
 cut-off interacts in one run and not in the other, which moves two cells by 0.5 dt at once
@@ -34,17 +36,26 @@ if __name__ == "__main__":
         steps = int(rng.integers(1, 13))
         dt = float(rng.choice([0.001, 0.004]))
         every = int(rng.choice([1, 2, 4]))
-        case = dict(n=n, world=world, steps=steps, dt=dt, migrate_every=every, seed=seed)
-        X0, Xref = test_slab.reference_run(device, n, 50, 0.5, 3, dt, steps)
+        # (drawn last, so that the cases of earlier logs keep their seeds) every third case runs the model
+        # without jumps at the cut-off, over more steps: no cell may differ there
+        strict = rng.random() < 1 / 3
+        model = "fading_grid" if strict else "springs_grid"
+        if strict:
+            steps, dt = 3 * steps, 5 * dt
+        case = dict(n=n, world=world, steps=steps, dt=dt, migrate_every=every, seed=seed, model=model)
+        X0, Xref = test_slab.reference_run(device, n, 50, 0.5, 3, dt, steps, model=model)
         bounds = test_slab.slab_mod.slab_bounds(X0[:, 2], world)
         if world > 2 and np.diff(bounds[1:-1]).min() < 1.25:
             print("skip", case, "(a slab thinner than the ghost layer: Slab() refuses)", flush=True)
             continue
-        X, moved = test_slab.slab_run(device, X0, world, 50, dt, steps, "hip", every)
+        X, moved = test_slab.slab_run(device, X0, world, 50, dt, steps, "hip", every, model=model)
         diff = np.abs(X - Xref).max(axis=1)
         scale = np.abs(Xref).max()
         off = int((diff > 1e-5 * scale).sum())
-        ok = off <= max(4, n // 2000, int(4 * steps * n / 40000)) and diff.max() <= 2.0 * steps * dt
+        if strict:
+            ok = diff.max() <= 2e-6 * scale
+        else:
+            ok = off <= max(4, n // 2000, int(4 * steps * n / 40000)) and diff.max() <= 2.0 * steps * dt
         bad += not ok
         print("ok  " if ok else "FAIL", case, "moved", moved, "cells beyond 1e-5:", off,
               "max diff %.2e" % diff.max(), flush=True)

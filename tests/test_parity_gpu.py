@@ -61,7 +61,7 @@ def test_springs_tile_bit_exact(oracle, device, n, steps):
 
 
 @pytest.mark.parametrize("model", ["clipped_grid", "relu_grid", "relu_po_grid", "relu_tile",
-                                   "relu_po_tile", "clipped_tile"])
+                                   "relu_po_tile", "clipped_tile", "fading_grid", "fading_tile"])
 def test_other_functors_bit_exact(oracle, device, model):
     n = 1000
     (Xo, vo, _), (Xd, vd, _) = run_both(oracle, device, model, n, 50, 1.0, 0.6, 5, 0.1, 3)

@@ -69,6 +69,25 @@ def test_slabs_match_undivided_system_oracle(oracle, world, n):
     check(oracle, n, world, 4, 0.002)
 
 
+def check_strictly(lib, n, world, steps, dt, device="cpu", migrate_every=1):
+    """fading_grid: a force that fades to zero at the cut-off and friction_on_background.  Nothing about a
+    pair jumps when it crosses the cut-off, so NO cell may differ: 2e-6 of the system's extent (the centre
+    of mass is summed in another association across slabs, 1e-7 per step) for every cell, over as many
+    steps as it takes for hundreds of cells to change their owner."""
+    X0, Xref = reference_run(lib, n, 50, 0.5, 3, dt, steps, model="fading_grid")
+    X, moved = slab_run(lib, X0, world, 50, dt, steps, device, migrate_every, model="fading_grid")
+    scale = np.abs(Xref).max()
+    assert np.abs(Xref - X0).max() > 0.1, "the system hardly moved: the case checks nothing"
+    assert np.abs(X - Xref).max() <= 2e-6 * scale, np.abs(X - Xref).max() / scale
+    return moved
+
+
+@pytest.mark.parametrize("world,n,steps,dt,migrate_every", [(3, 3000, 30, 0.01, 1), (5, 9000, 30, 0.02, 4),
+                                                            (2, 6000, 40, 0.02, 8)])
+def test_slabs_match_undivided_system_strictly_oracle(oracle, world, n, steps, dt, migrate_every):
+    assert check_strictly(oracle, n, world, steps, dt, migrate_every=migrate_every) > 20
+
+
 def test_slabs_of_five_float_points_oracle(oracle):
     """Po_cell (20-byte points: position + polarity) through the decomposition: messages, mirrored
     rows and updates are sized by the point type."""
@@ -327,6 +346,13 @@ def test_two_ranks_over_rccl_match_undivided_system(device, tmp_path):
     assert np.array_equal(got["X0"], X0)
     scale = np.abs(Xref).max()
     assert np.abs(got["X"] - Xref).max() <= 1e-5 * scale
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,n,steps,dt,migrate_every", [(6, 40000, 40, 0.02, 4), (3, 20000, 30, 0.01, 1),
+                                                            (8, 150000, 24, 0.02, 8)])
+def test_slabs_match_undivided_system_strictly_device(device, world, n, steps, dt, migrate_every):
+    assert check_strictly(device, n, world, steps, dt, device="hip", migrate_every=migrate_every) > 20
 
 
 @pytest.mark.gpu

@@ -48,6 +48,19 @@ __device__ inline float3 clipped_spring(float3 Xi, float3 r, float dist, int i, 
     return dF;
 }
 
+// A spring whose force fades to zero at the cut-off (NOT a reference model: the z-slab decomposition's
+// tests use it with friction_on_background).  Nothing about such a pair changes by a jump when it crosses
+// the cut-off, so a divided run has no pair "within rounding of the cut-off" to excuse a cell that differs
+// from the undivided run: the comparison is strict (tests/test_slab.py, tests/fuzz_slab.py).
+__device__ inline float3 fading_spring(float3 Xi, float3 r, float dist, int i, int j)
+{
+    float3 dF{0.f, 0.f, 0.f};
+    if (i == j) return dF;
+    if (dist >= 1) return dF;
+    dF = r * ((L_0 - dist) * (1 - dist)) / dist;
+    return dF;
+}
+
 // --- sorting: examples/sorting.cu:9-28 (differential adhesion between two cell
 // types; the first half of the ids is the strongly adhering type).  n_cells is
 // a compile-time constant in the example and a model parameter here. -----------
@@ -414,6 +427,7 @@ inline void proliferate(float rate, double mean_dist, unsigned seed, unsigned st
 #ifdef YA_STATELESS
 YA_STATELESS(float3, models::spring)
 YA_STATELESS(float3, models::clipped_spring)
+YA_STATELESS(float3, models::fading_spring)
 YA_STATELESS(float3, models::differential_adhesion)
 YA_STATELESS(float3, relu_force<float3>)
 YA_STATELESS(Po_cell, relu_force<Po_cell>)
