@@ -1,6 +1,6 @@
 """A THIRD statement of the step itself: `Heun_solver::take_step` with its default friction, written in numpy
-float64 straight from the reference (include/solvers.cuh:113-161 euler_step / heun_step / add_rhs, :226-322
-take_step, :349-378 compute_tile, :430-463 compute_cube) -- not from include/solvers.cuh of this repository or
+float64 straight from the reference (include/solvers.cuh:113-161 euler_step / heun_step / add_rhs, :226-277
+take_step, :284-322 compute_tile, :430-463 compute_cube) -- not from include/solvers.cuh of this repository or
 oracle/yalla_host.hpp.  tests/test_model_functors_independent.py does this for the model functors with the
 velocities at zero; here the velocities are what is looked at: several steps of springs under
 friction_w_neighbour, so that every stage averages the neighbours' old velocities, with the centre of mass,
@@ -46,7 +46,7 @@ def right_hand_side(X, old_v, cut_off, links=None):
     neighbours' old velocities."""
     n = len(X)
     dX = np.zeros_like(X)
-    gen = link_forces(X, *links) if links is not None else dX  # solvers.cuh:262, :291: before pwints, into d_dX
+    gen = link_forces(X, *links) if links is not None else dX  # solvers.cuh:235, :261: before pwints, into d_dX
     for i in range(n):
         F, sum_v, sum_friction = np.zeros(3), np.zeros(3), 0.0
         for j in range(n):
@@ -59,29 +59,29 @@ def right_hand_side(X, old_v, cut_off, links=None):
             sum_friction += friction
             sum_v += friction * old_v[j]
         dX[i] = gen[i] + F
-        if sum_friction > 0:  # add_rhs :152-160
+        if sum_friction > 0:  # add_rhs :146-161
             dX[i] += sum_v / sum_friction
     return dX
 
 
 def take_step(X, old_v, dt, cut_off, fix, links=None):
-    """solvers.cuh:226-322.  fix = ("com",) | ("point", id) | ("point_xy", id)."""
+    """solvers.cuh:226-277.  fix = ("com",) | ("point", id) | ("point_xy", id)."""
     dX = right_hand_side(X, old_v, cut_off, links)
     if fix[0] == "com":
         fix_dX = dX.mean(axis=0)
     elif fix[0] == "point":
         fix_dX = dX[fix[1]].copy()
-    else:  # set_fixed_xy :241-253, :266-272: the centre of mass, x and y overwritten by the point's
+    else:  # set_fixed_xy :203-208, take_step :241-250: the centre of mass, x and y overwritten by the point's
         fix_dX = dX.mean(axis=0)
         fix_dX[:2] = dX[fix[1], :2]
-    dX = dX - fix_dX  # euler_step :117-128
+    dX = dX - fix_dX  # euler_step :113-125
     X1 = X + dX * dt
     dX1 = right_hand_side(X1, old_v, cut_off, links)
     if fix[0] == "com":
         fix_dX1 = dX1.mean(axis=0)
-    else:  # :300-306: `if (fix_com)` -- false after set_fixed_xy too, so the SECOND stage holds the point
+    else:  # :266-272: `if (fix_com)` -- false after set_fixed_xy too, so the SECOND stage holds the point
         fix_dX1 = dX1[fix[1]].copy()
-    dX1 = dX1 - fix_dX1  # heun_step :130-146
+    dX1 = dX1 - fix_dX1  # heun_step :127-144
     return X + (dX + dX1) * 0.5 * dt, (dX + dX1) * 0.5
 
 
