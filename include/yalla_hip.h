@@ -117,7 +117,7 @@ int ya_grid_build(ya_grid* g, const void* d_X, size_t stride_bytes, int n,
 /* ya_grid_build + a gather of the cells into sorted order for the force
  * kernel: d_sorted_X[slot] = { point (stride_bytes), int point_id, padding up
  * to entry_bytes }, d_sorted_v[slot] = { old_v.x, old_v.y, old_v.z, 0 } (16 B).
- * d_old_v is the float3 array of solvers.cuh:66 (12-byte elements). */
+ * d_old_v is the float3 array of solvers.cuh:65 (12-byte elements). */
 int ya_grid_build_sorted(ya_grid* g, const void* d_X, size_t stride_bytes,
     const void* d_old_v, int n, float cube_size, void* d_sorted_X,
     size_t entry_bytes, void* d_sorted_v, void* stream);
@@ -160,7 +160,7 @@ int ya_grid_forget_order(ya_grid* g);
  * full scan is 2 x 15 us of its 0.9 ms step at 10 M cells in 8 slabs.  A cell outside the range
  * raises YA_STATUS_OUT_OF_RANGE and is binned into the range's first or last cube (memory-safe,
  * like a cell outside the grid).  (0, n_cubes) or wider removes the promise.  New relative to the
- * reference (single GPU: its two thrust::fill of gs^3 ints per build, solvers.cuh:409-412). */
+ * reference (single GPU: its two thrust::fill of gs^3 ints per build, solvers.cuh:411-412). */
 int ya_grid_set_cube_range(ya_grid* g, int cube_lo, int cube_hi);
 
 /* Sticky status bits (YA_STATUS_*); blocking 4-byte read.  `clear` != 0
