@@ -174,6 +174,9 @@ def parse(argv=None):
                          "the same system with dt = 0, i.e. every step recomputes the same state (forces, both grid "
                          "builds, reductions, updates: all the work, none of the drift of the clumping springs system), "
                          "with the shader clock sampled beside it (ya_shader_clock_mhz) so that throttling shows")
+    ap.add_argument("--no-fast-tier-line", action="store_true",
+                    help="headline run: skip the extra, untimed-by-the-contract pass on the fast-arithmetic build "
+                         "(reported as fast_arith_tier beside the headline value)")
     ap.add_argument("--graph", type=int, default=0,
                     help="Heun_solver::graph_steps: 1 = replay the step as a hipGraph, -1 = below 400 k "
                          "cells only, 0 = plain launches (default)")
@@ -701,6 +704,27 @@ def main(argv=None):
             out["speedup_vs_one_gpu_same_system"] = value / one_gpu if one_gpu else None
         if counters.get("stale_counters"):
             out["roofline"]["stale_counters"] = True
+        if (world == 1 and not args.slab and not args.sustained and not args.no_fast_tier_line and state is None
+                and args.model == "springs_grid" and args.arith == "exact" and args.renumber_every == 0):
+            # beside the headline, never instead of it: the same steps on the fast-arithmetic build of the same
+            # sources (what nvcc's default contraction and norm3df give the reference's own CUDA build)
+            sim.close()
+            with _Solution(args.model, n_total, gs, 1.0, lib=_ffi.device_lib("fast")) as fast:
+                fast.random_sphere(args.dist, 42)
+                fast.set_param("force_variant", args.force_variant)
+                fast.set_param("sorted_pipeline", args.sorted_pipeline)
+                fast.take_step(dt, args.warmup)
+                fast.synchronize()
+                t1 = time.perf_counter()
+                fast.take_step(dt, args.steps)
+                fast.synchronize()
+                fast_s = time.perf_counter() - t1
+            out["fast_arith_tier"] = {
+                "value": n_total * args.steps / fast_s, "unit": "cell-updates/s", "ms_per_step": fast_s / args.steps * 1e3,
+                "what": "libyalla_models_fast.so: the same sources with -DYA_ARITH_FAST -ffp-contract=fast (bare v_sqrt_f32 / "
+                        "v_rcp_f32, contracted multiply-adds); positions within 1e-5 relative of the exact tier in lock-step, "
+                        "cube ids and cell counts bit-exact (tests/test_fast_arith_gpu.py).  Not the headline: `value` above "
+                        "is the exact tier, bit-comparable with the CPU oracle"}
         if world == 1 and not args.slab and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.model, n_total, gs, args.dist, dt, args.cpu_steps, state,
                                                args.renumber_every)
