@@ -15,4 +15,4 @@ touch oracle/_build/liboracle_models.so
 LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)" \
 ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
 python -m pytest tests/test_oracle_kats.py tests/test_golden.py tests/test_growth.py \
-    tests/test_model_functors_independent.py tests/test_slab.py -q -m "not gpu" -k "not gloo" -p no:cacheprovider
+    tests/test_model_functors_independent.py tests/test_heun_independent.py tests/test_slab.py -q -m "not gpu" -k "not gloo" -p no:cacheprovider
