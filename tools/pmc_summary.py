@@ -7,7 +7,12 @@ def main(paths, filt):
         for r in csv.DictReader(open(p)):
             k = r['Kernel_Name']
             if filt and filt not in k: continue
-            agg[k[:60]][r['Counter_Name']].append(float(r['Counter_Value']))
+            # template arguments that tell two builds of one kernel apart sit at the END of the argument list
+            # (demangled: before the '('; mangled: before the 'EEv' that opens the parameter list)
+            head = k.split('(')[0]
+            if head.startswith('_Z') and 'EEv' in head: head = head[:head.rindex('EEv')]
+            key = head if len(head) <= 60 else head[:40] + ' ... ' + head[-24:]
+            agg[key][r['Counter_Name']].append(float(r['Counter_Value']))
     for k, cs in agg.items():
         print(k)
         for c, v in sorted(cs.items()):
