@@ -12,8 +12,8 @@
 //              little between builds), so a wavefront's 64 atomics fall on a
 //              few neighbouring counters instead of 64 random cache lines, and
 //              the later scatter writes neighbouring slots
-//   k_tile_sum per-tile totals of count[] (tile = 2048 cubes)
-//   k_scan     exclusive prefix -> offs[], cube_start[], cube_end[] for EVERY
+//   k_scan     per-tile totals of count[] (tile = 2048 cubes), published and collected inside the
+//              one launch; exclusive prefix -> offs[], cube_start[], cube_end[] for EVERY
 //              cube (so no fills are needed), and count[] re-zeroed in passing
 //   k_scatter  slot = offs[cube] + rank (arrival order inside a cube)
 //   k_order    restores ascending point id inside each cube (what a stable
@@ -131,32 +131,22 @@ __device__ __forceinline__ int block_sum(int v, int* sh)
     return sh[0] + sh[1] + sh[2] + sh[3];
 }
 
+// Round 5: the tile totals and the prefix in ONE launch (they were k_tile_sum and k_scan, two launches
+// of a few microseconds of work each, twice per take_step).  Every block publishes its tile's total
+// first -- one 64-bit word {1, total}, stored and read past the XCDs' L2s (device-scope atomics) -- and
+// then collects the totals of the tiles before it, waiting for those not yet there.  A block only ever
+// waits for blocks with LOWER indices, which the dispatcher started before it and which publish before
+// they wait themselves: no cycle.  The block that is through last (a ticket) clears the words again.
 // (first_tile: the scan of a cube range, ya_grid_set_cube_range -- block b works on tile first_tile + b)
-__global__ __launch_bounds__(BLOCK) void k_tile_sum(
-    const int* __restrict__ count, int* __restrict__ tile_sums, int first_tile)
-{
-    __shared__ int sh[4];
-    const int tile = first_tile + blockIdx.x;
-    const int4* c4 = reinterpret_cast<const int4*>(count + (size_t)tile * SCAN_TILE);
-    int4 a = c4[threadIdx.x * 2], b = c4[threadIdx.x * 2 + 1];
-    int v = a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
-    int s = block_sum(v, sh);
-    if (threadIdx.x == 0) tile_sums[tile] = s;
-}
-
 __global__ __launch_bounds__(BLOCK) void k_scan(int* __restrict__ count,
-    const int* __restrict__ tile_sums, int n_cubes, int n, int* __restrict__ offs,
-    int* __restrict__ cube_start, int* __restrict__ cube_end, const int* __restrict__ d_n,
-    int first_tile, int all_tiles)
+    unsigned long long* __restrict__ tile_state, int* __restrict__ ticket, int n_cubes, int n,
+    int* __restrict__ offs, int* __restrict__ cube_start, int* __restrict__ cube_end,
+    const int* __restrict__ d_n, int first_tile, int all_tiles)
 {
     if (d_n) n = min(*d_n, n);
     __shared__ int sh[4];
     __shared__ int sh_wave[4];
-    // cells in all tiles before this one (a cube range: no cell lies below its first tile)
     const int tile = first_tile + blockIdx.x;
-    int before = 0;
-    for (int t = first_tile + threadIdx.x; t < tile; t += BLOCK) before += tile_sums[t];
-    before = block_sum(before, sh);
 
     size_t base = (size_t)tile * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
     int4* c4 = reinterpret_cast<int4*>(count + base);
@@ -165,7 +155,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan(int* __restrict__ count,
     int total = 0;
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; k++) total += c[k];
-    // exclusive scan of the 256 thread totals: inclusive wave scan + wave offsets
+    // inclusive scan of the 256 thread totals inside each wavefront; the wavefronts' totals
     int incl = total;
     int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int o = 1; o < 64; o <<= 1) {
@@ -174,6 +164,19 @@ __global__ __launch_bounds__(BLOCK) void k_scan(int* __restrict__ count,
     }
     if (lane == 63) sh_wave[w] = incl;
     __syncthreads();
+    if (threadIdx.x == 0)
+        __hip_atomic_store(&tile_state[tile],
+            (1ULL << 32) | (unsigned)(sh_wave[0] + sh_wave[1] + sh_wave[2] + sh_wave[3]), __ATOMIC_RELAXED,
+            __HIP_MEMORY_SCOPE_AGENT);
+    // cells in all tiles before this one (a cube range: no cell lies below its first tile)
+    int before = 0;
+    for (int t = first_tile + threadIdx.x; t < tile; t += BLOCK) {
+        unsigned long long v;
+        while (!((v = __hip_atomic_load(&tile_state[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32))
+            __builtin_amdgcn_s_sleep(1);
+        before += (int)(unsigned)v;
+    }
+    before = block_sum(before, sh);
     int wave_off = 0;
     for (int k = 0; k < w; k++) wave_off += sh_wave[k];
     int run = before + wave_off + incl - total;
@@ -199,6 +202,16 @@ __global__ __launch_bounds__(BLOCK) void k_scan(int* __restrict__ count,
     c4[1] = make_int4(0, 0, 0, 0);
     if (tile == all_tiles - 1 && threadIdx.x == BLOCK - 1)
         offs[(size_t)all_tiles * SCAN_TILE] = n;
+    // the block that is through last leaves the published totals cleared for the next scan (block_sum's
+    // barriers lie between every thread's reads of them and this ticket)
+    __shared__ int sh_last;
+    if (threadIdx.x == 0) sh_last = atomicAdd(ticket, 1) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (sh_last) {
+        for (int t = first_tile + threadIdx.x; t < first_tile + (int)gridDim.x; t += BLOCK)
+            __hip_atomic_store(&tile_state[t], 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 __global__ __launch_bounds__(BLOCK) void k_scatter(const int* __restrict__ cube_of,
@@ -318,6 +331,12 @@ __device__ __forceinline__ void fold256(float (&acc)[NW], float* sh /* [NW][256]
     }
 }
 
+// (Round 5 tried ONE launch -- the block that draws the last ticket folds the partials, same order --
+// and it is slower, 13.6 us against 9.8 for the two launches at 1024 blocks: partial sums that cross
+// XCDs must go past the L2s (device-scope stores, an acknowledged write, tickets drawn one after the
+// other, uncached loads), 8-9 us of serial round trips where a launch of one block costs 4.9; with
+// __threadfence() instead, 66 us: every block writes back and invalidates its XCD's L2.
+// profiles/r05_nonforce_ab.jsonl)
 template<int NW>
 __global__ __launch_bounds__(BLOCK) void k_reduce_partial(
     const float* __restrict__ v, int n, float* __restrict__ partials)
@@ -749,7 +768,9 @@ struct ya_grid {
     int n_max, grid_size, n_cubes, n_tiles;
     size_t padded;  // n_cubes rounded up to whole scan tiles
     int *d_cube_id, *d_point_id, *d_cube_start, *d_cube_end;  // public
-    int *d_offs, *d_count, *d_tile_sums;                      // private
+    int *d_offs, *d_count;                                    // private
+    unsigned long long* d_tile_state;  // k_scan: a tile's published total, [n_tiles]; zero between scans
+    int* d_scan_ticket;
     int *d_cube_of, *d_rank, *d_arrival;                      // private, [n_max]
     int *d_arrival_src;  // visit position of the cell that arrived in a slot
     float* d_stash;      // the points in visit order (ya_grid_build_sorted), lazily sized
@@ -865,7 +886,10 @@ static int grid_allocate(ya_grid* g, int n_max)
     YA_TRY(hipMalloc(&g->d_cube_end, cb));
     YA_TRY(hipMalloc(&g->d_offs, cb));
     YA_TRY(hipMalloc(&g->d_count, cb));
-    YA_TRY(hipMalloc(&g->d_tile_sums, (size_t)g->n_tiles * sizeof(int)));
+    YA_TRY(hipMalloc(&g->d_tile_state, (size_t)g->n_tiles * sizeof(unsigned long long)));
+    YA_TRY(hipMalloc(&g->d_scan_ticket, sizeof(int)));
+    YA_TRY(hipMemset(g->d_tile_state, 0, (size_t)g->n_tiles * sizeof(unsigned long long)));
+    YA_TRY(hipMemset(g->d_scan_ticket, 0, sizeof(int)));
     YA_TRY(hipMalloc(&g->d_status, sizeof(int)));
     YA_TRY(hipMemset(g->d_count, 0, cb));
     YA_TRY(hipMemset(g->d_offs, 0, cb));
@@ -925,7 +949,8 @@ int ya_grid_destroy(ya_grid* g)
     (void)hipFree(g->d_cube_end);
     (void)hipFree(g->d_offs);
     (void)hipFree(g->d_count);
-    (void)hipFree(g->d_tile_sums);
+    (void)hipFree(g->d_tile_state);
+    (void)hipFree(g->d_scan_ticket);
     (void)hipFree(g->d_status);
     free(g);
     return 0;
@@ -955,8 +980,7 @@ static void launch_scan(ya_grid* g, int n, const int* d_n, hipStream_t st)
     const bool range_only = g->range_n >= 0 && g->range_n == n && !d_n;
     const int first = range_only ? g->range_first_tile : 0;
     const int tiles = range_only ? g->range_end_tile - g->range_first_tile : g->n_tiles;
-    k_tile_sum<<<tiles, BLOCK, 0, st>>>(g->d_count, g->d_tile_sums, first);
-    k_scan<<<tiles, BLOCK, 0, st>>>(g->d_count, g->d_tile_sums, g->n_cubes, n, g->d_offs, g->d_cube_start,
+    k_scan<<<tiles, BLOCK, 0, st>>>(g->d_count, g->d_tile_state, g->d_scan_ticket, g->n_cubes, n, g->d_offs, g->d_cube_start,
         g->d_cube_end, d_n, first, g->n_tiles);
     if (!range_only && g->range_first_tile >= 0) g->range_n = d_n ? -1 : n;
 }
