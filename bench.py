@@ -174,6 +174,10 @@ def parse(argv=None):
                          "the same system with dt = 0, i.e. every step recomputes the same state (forces, both grid "
                          "builds, reductions, updates: all the work, none of the drift of the clumping springs system), "
                          "with the shader clock sampled beside it (ya_shader_clock_mhz) so that throttling shows")
+    ap.add_argument("--no-sustained-line", action="store_true",
+                    help="headline run: skip the extra pass, outside the timed region, of --sustained-steps take_steps "
+                         "with dt = 0 (reported as `sustained` beside the headline value)")
+    ap.add_argument("--sustained-steps", type=int, default=3000)
     ap.add_argument("--no-fast-tier-line", action="store_true",
                     help="headline run: skip the extra, untimed-by-the-contract pass on the fast-arithmetic build "
                          "(reported as fast_arith_tier beside the headline value)")
@@ -435,6 +439,31 @@ def main(argv=None):
             native_comm = slab_mod.NativeComm(port_offset=1)
         assert (native_comm.rank, native_comm.world) == (rank, world)
 
+    # What RCCL itself says about the job (ya_comm_info -> ncclCommCount / ncclCommUserRank /
+    # ncclCommCuDevice + the PCI location of that device), gathered over the communicator: the line
+    # carries it as "rccl", and a job whose communicator does not span --gpus ranks on as many
+    # distinct GPUs stops here instead of reporting a number for something else.
+    rccl_facts = None
+    if native_comm is not None and world > 1:
+        gathered = native_comm.gather_info()
+        devices = [g["pci_bus_id"] for g in gathered]
+        rccl_facts = {"ranks": gathered[0]["ranks"], "user_ranks": [g["rank"] for g in gathered],
+                      "devices": devices, "hip_devices": [g["device"] for g in gathered],
+                      "how": "ncclCommCount / ncclCommUserRank / ncclCommCuDevice of every rank's communicator, "
+                             "all-gathered over it (libyalla_hip.so: ya_comm_info)"}
+        problems = []
+        if any(g["ranks"] != args.gpus for g in gathered) or len(gathered) != args.gpus:
+            problems.append(f"ncclCommCount says {[g['ranks'] for g in gathered]}, --gpus is {args.gpus}")
+        if [g["rank"] for g in gathered] != list(range(world)):
+            problems.append(f"ncclCommUserRank says {[g['rank'] for g in gathered]}")
+        if len(set(devices)) != world and "YALLA_BENCH_DEVICE" not in os.environ:
+            problems.append(f"ranks share a GPU: {devices}")
+        if problems:
+            sys.exit("bench.py: the RCCL communicator is not what --gpus promises: " + "; ".join(problems))
+    elif slab_path and world > 1:
+        rccl_facts = {"ranks": None, "devices": None,
+                      "how": f"rehearsal mode: messages over {args.backend}, no RCCL communicator"}
+
     def barrier():
         torch.cuda.synchronize()
         if native_comm is not None:
@@ -453,11 +482,17 @@ def main(argv=None):
         dist.all_reduce(t, op=dist.ReduceOp.MAX if take_max else dist.ReduceOp.SUM)
         return float(t.item())
 
-    if not slab_path:
+    n_links = 0
+    link_pairs = None
+
+    def make_sim(lib=None):
+        """The undivided system of this run, ready for its first step (called again for the untimed
+        passes that repeat the timed steps: force-kernel events, the fast tier)."""
+        nonlocal n_links, link_pairs
         if state is not None:
-            sim = cases.from_state(state, engine)
+            sim = cases.from_state(state, lib or engine)
         else:
-            sim = Solution(args.model, n_total, gs, 1.0)
+            sim = Solution(args.model, n_total, gs, 1.0, lib=lib or engine)
             sim.random_sphere(args.dist, 42)
         if "grid" in args.model:
             sim.set_param("force_variant", args.force_variant)
@@ -474,22 +509,27 @@ def main(argv=None):
             sim.set_param("renumber_every", args.renumber_every)
         if args.model.endswith("_tile") and args.tile_lanes != 1:
             sim.set_param("tile_lanes", args.tile_lanes)
-        n_links = 0
         if args.model == "springs_links_grid" and args.links_per_cell > 0:
-            # every cell linked to its k nearest neighbours (as the protrusions of
-            # examples/intercalation.cu:32-68 link nearby cells), fixed for the run
-            import numpy as np
-            from scipy.spatial import cKDTree
-            X = sim.h_X[:n_total].copy()
-            _, idx = cKDTree(X).query(X, k=args.links_per_cell + 1)
-            pairs = np.stack([np.repeat(np.arange(n_total), args.links_per_cell),
-                              idx[:, 1:].reshape(-1)], axis=1).astype(np.int32)
-            if args.link_order == "shuffled":     # as a model's protrusions are: no order at all
-                pairs = pairs[np.random.default_rng(7).permutation(len(pairs))]
-            elif args.link_order == "by-min":     # sorted by the smaller cell id of the pair
-                pairs = pairs[np.argsort(pairs.min(axis=1), kind="stable")]
-            sim.set_links(pairs, 0.2)
-            n_links = len(pairs)
+            if link_pairs is None:
+                # every cell linked to its k nearest neighbours (as the protrusions of
+                # examples/intercalation.cu:32-68 link nearby cells), fixed for the run
+                import numpy as np
+                from scipy.spatial import cKDTree
+                X = sim.h_X[:n_total].copy()
+                _, idx = cKDTree(X).query(X, k=args.links_per_cell + 1)
+                pairs = np.stack([np.repeat(np.arange(n_total), args.links_per_cell),
+                                  idx[:, 1:].reshape(-1)], axis=1).astype(np.int32)
+                if args.link_order == "shuffled":     # as a model's protrusions are: no order at all
+                    pairs = pairs[np.random.default_rng(7).permutation(len(pairs))]
+                elif args.link_order == "by-min":     # sorted by the smaller cell id of the pair
+                    pairs = pairs[np.argsort(pairs.min(axis=1), kind="stable")]
+                link_pairs = pairs
+            sim.set_links(link_pairs, 0.2)
+            n_links = len(link_pairs)
+        return sim
+
+    if not slab_path:
+        sim = make_sim()
 
         def advance(k):
             sim.take_step(dt, k)
@@ -527,32 +567,45 @@ def main(argv=None):
     advance(args.warmup)
     barrier()
     # The engine replays small systems' steps as a hipGraph (Heun_solver::graph_steps), which
-    # per-launch events would switch off: time those without events and measure the force
-    # kernel in a second, untimed pass of plain launches.
+    # per-launch events would switch off.
     graph_mode = (not slab_path and "grid" in args.model and
                   (args.graph == 1 or (args.graph == -1 and n_total < 400_000)))
-    if not graph_mode:
-        # HIP events on every 5th launch of the force kernel (both stages alternate):
-        # a timed launch costs a few microseconds of stream time, see DESIGN.md section 6
-        sim.profile(True, every=args.time_every)
     clock_samples = []
     sampler = None
-    if args.sustained and rank == 0:
+    stop_sampling = None
+
+    def start_clock_sampler():
+        """The shader clock beside a run: a wavefront of its own on a stream of its own, every 50 ms
+        (ya_shader_clock_mhz probes the device that is current for the calling thread)."""
         import ctypes as C
         import threading
         core = C.CDLL(_ffi.CORE_LIB, mode=C.RTLD_LOCAL)
         core.ya_shader_clock_mhz.argtypes = [C.c_double, C.POINTER(C.c_double)]
-        stop_sampling = threading.Event()
+        stop = threading.Event()
+        samples = []
 
-        def sample_clock():   # beside the steps: a wavefront of its own on a stream of its own
+        def sample_clock():
+            torch.cuda.set_device(local_rank)   # a new thread starts on device 0
             mhz = C.c_double()
-            while not stop_sampling.is_set():
+            while not stop.is_set():
                 if core.ya_shader_clock_mhz(200.0, C.byref(mhz)) == 0:
-                    clock_samples.append(mhz.value)
-                stop_sampling.wait(0.05)
+                    samples.append(mhz.value)
+                stop.wait(0.05)
 
-        sampler = threading.Thread(target=sample_clock, daemon=True)
-        sampler.start()
+        thread = threading.Thread(target=sample_clock, daemon=True)
+        thread.start()
+        return thread, stop, samples
+
+    def clock_summary(samples):
+        cs = sorted(samples)
+        return {"samples": len(cs), "min": cs[0] if cs else None, "median": cs[len(cs) // 2] if cs else None,
+                "max": cs[-1] if cs else None,
+                "how": "ya_shader_clock_mhz: s_memtime against the 100 MHz wall clock, one wavefront beside the run, "
+                       "every 50 ms"}
+
+    if args.sustained and rank == 0:
+        sampler, stop_sampling, clock_samples = start_clock_sampler()
+    # ---- the timed region: K steps, nothing else (no events, no host work but take_step's own) ----
     t0 = time.perf_counter()
     advance(args.steps)
     barrier()
@@ -560,10 +613,26 @@ def main(argv=None):
     if sampler is not None:
         stop_sampling.set()
         sampler.join()
-    if graph_mode:
-        sim.profile(True, every=1)
-        advance(min(args.steps, 10))
+    # The force kernel's launch time: HIP events attached to the kernel's own dispatch on the stream it
+    # is launched on -- in a SECOND, untimed pass.  On one GPU that pass repeats the timed region on a
+    # fresh copy of the system (same seed, same warm-up, the same K steps: the launches measured are
+    # the launches that were timed; events on every launch cost ~24 us of stream time per step, which
+    # is why they are not inside the timed region any more).  On the z-slab path and in graph mode it
+    # continues from the state the timed region left.
+    if not slab_path and not graph_mode and not args.sustained:
+        sim.close()
+        sim = make_sim()
+        advance(args.warmup)
         barrier()
+        sim.profile(True, every=1)
+        advance(args.steps)
+        barrier()
+        events_pass = "the timed steps repeated on a fresh copy of the system, events on every force launch"
+    else:
+        sim.profile(True, every=1 if graph_mode else args.time_every)
+        advance(min(args.steps, 10 if graph_mode or slab_path else 20))
+        barrier()
+        events_pass = "steps after the timed region, from the state it left"
     force_ms, launches = sim.profile_read()
     sim.profile(False)
     if not slab_path:
@@ -664,6 +733,7 @@ def main(argv=None):
                                        "upper bound of the stage's force time, so `achieved` is a lower bound"}
                    if split_force else {}),
                 "timed_launches": launches,
+                "events_pass": events_pass,
                 "launches": (4 if split_force else 2) * args.steps,
                 "whole_step_achieved_GBs": step_bytes_per_cell(n_floats) * value / world / 1e9,
                 # SURVEY.md §8(d)'s second, explicitly labelled figure: bytes the reference's
@@ -690,29 +760,54 @@ def main(argv=None):
             },
         }
         if args.sustained:
-            cs = sorted(clock_samples)
             out["sustained"] = {
                 "seconds": elapsed,
                 "what": "dt = %g: every take_step does all its work on the same state (no drift of the workload)" % dt,
-                "shader_clock_mhz": {"samples": len(cs), "min": cs[0] if cs else None,
-                                     "median": cs[len(cs) // 2] if cs else None, "max": cs[-1] if cs else None,
-                                     "how": "ya_shader_clock_mhz: s_memtime against the 100 MHz wall clock, one wavefront "
-                                            "beside the run, every 50 ms"},
+                "shader_clock_mhz": clock_summary(clock_samples),
             }
+        if rccl_facts is not None:
+            out["rccl"] = rccl_facts
         if world > 1:
             out["one_gpu_same_system"] = one_gpu
             out["speedup_vs_one_gpu_same_system"] = value / one_gpu if one_gpu else None
         if counters.get("stale_counters"):
             out["roofline"]["stale_counters"] = True
-        if (world == 1 and not args.slab and not args.sustained and not args.no_fast_tier_line and state is None
-                and args.model == "springs_grid" and args.arith == "exact" and args.renumber_every == 0):
+        headline = (world == 1 and not args.slab and not args.sustained and state is None
+                    and args.model == "springs_grid" and args.arith == "exact" and args.renumber_every == 0)
+        if headline and not args.no_sustained_line:
+            # Beside the headline, never instead of it, and outside its timed region: the figure that does not
+            # drift.  --sustained-steps take_steps with dt = 0 on a fresh copy of the system -- every step
+            # recomputes the same rho ~ 9.8 state: both grid builds, both force launches, reductions, updates --
+            # with the shader clock sampled beside the run, then a few more steps with events for the launch time.
+            sim.close()
+            sim = make_sim()
+            sim.take_step(0.0, args.warmup)
+            sim.synchronize()
+            thread, stop, samples = start_clock_sampler()
+            t1 = time.perf_counter()
+            sim.take_step(0.0, args.sustained_steps)
+            sim.synchronize()
+            sustained_s = time.perf_counter() - t1
+            stop.set()
+            thread.join()
+            sim.profile(True, every=1)
+            sim.take_step(0.0, 20)
+            sim.synchronize()
+            s_ms, s_launches = sim.profile_read()
+            sim.profile(False)
+            out["sustained"] = {
+                "value": n_total * args.sustained_steps / sustained_s, "unit": "cell-updates/s",
+                "ms_per_step": sustained_s / args.sustained_steps * 1e3, "steps": args.sustained_steps,
+                "seconds": sustained_s, "force_us": s_ms / max(s_launches, 1) * 1e3,
+                "shader_clock_mhz": clock_summary(samples),
+                "what": "dt = 0 on a fresh copy of the system: every take_step does all its work on the same state "
+                        "(40.2 pairs inside the cut-off per cell, no clumping), long enough for the clock to settle; "
+                        "`value` above is steps %d..%d of the moving system" % (args.warmup + 1, args.warmup + args.steps)}
+        if headline and not args.no_fast_tier_line:
             # beside the headline, never instead of it: the same steps on the fast-arithmetic build of the same
             # sources (what nvcc's default contraction and norm3df give the reference's own CUDA build)
             sim.close()
-            with _Solution(args.model, n_total, gs, 1.0, lib=_ffi.device_lib("fast")) as fast:
-                fast.random_sphere(args.dist, 42)
-                fast.set_param("force_variant", args.force_variant)
-                fast.set_param("sorted_pipeline", args.sorted_pipeline)
+            with make_sim(lib=_ffi.device_lib("fast")) as fast:
                 fast.take_step(dt, args.warmup)
                 fast.synchronize()
                 t1 = time.perf_counter()

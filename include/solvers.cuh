@@ -1844,7 +1844,10 @@ public:
         (void)unused;
         if (new_id) ya_free(new_id);
         Computer<Pt>::ids_changed();
+        // a graph captured NOW would bake the forgotten visit order (n_prev = 0) into its first build:
+        // capture again one step later, when the grid remembers an order again
         drop_graph();
+        last_key = Step_key{};
     }
 
     // Replaying the step as one hipGraph (Grid_solver without generic forces), opt-in:

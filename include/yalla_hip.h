@@ -29,7 +29,7 @@ extern "C" {
 /* The libraries are built with -fvisibility=hidden; only this C ABI is exported. */
 #pragma GCC visibility push(default)
 
-#define YA_ABI_VERSION 8  /* 8: + ya_grid_set_cube_range, YA_STATUS_OUT_OF_RANGE, the slab guard / fixed point / payload entries, ya_async_read_* */
+#define YA_ABI_VERSION 9  /* 9: + ya_comm_info; 8: + ya_grid_set_cube_range, YA_STATUS_OUT_OF_RANGE, the slab guard / fixed point / payload entries, ya_async_read_* */
 
 /* Status bits reported by ya_grid_status(). */
 #define YA_STATUS_OUT_OF_GRID 1 /* a cell's cube id fell outside [0, n_cubes):
@@ -340,6 +340,16 @@ int ya_comm_allreduce_sum(ya_comm* comm, float* d_buf, int count, void* stream);
 /* The same on host memory through the devices (a bounce buffer): for the few control values a
  * program needs once (timings, totals); blocking. */
 int ya_comm_allreduce_host(ya_comm* comm, double* values, int count, int take_max);
+/* What RCCL itself says about this communicator (so that a program can prove that N ranks sit on N
+ * distinct GPUs instead of trusting its environment variables):
+ *   info[0] = ncclCommCount, info[1] = ncclCommUserRank, info[2] = ncclCommCuDevice,
+ *   info[3] = the calling thread's current HIP device, info[4] = 1 for a real RCCL communicator,
+ *             0 for none (world 1 without an id) and 2 for a loopback one (then info[0..2] are its own
+ *             world, rank and current device),
+ *   info[5] = the device's PCI location as (domain << 16) | (bus << 8) | (device << 3) | function,
+ *   info[6], info[7] = 0;
+ * pci_bus_id (may be NULL): hipDeviceGetPCIBusId's string of info[2]'s device, at most 31 characters. */
+int ya_comm_info(const ya_comm* comm, int info[8], char pci_bus_id[32]);
 
 #pragma GCC visibility pop
 #ifdef __cplusplus

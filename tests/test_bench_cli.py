@@ -88,3 +88,22 @@ def test_self_launched_two_ranks_on_one_gpu(device):
     # the base of the strong-scaling curve travels with the line: the same system on one GPU
     assert out["one_gpu_same_system"] > 0
     assert abs(out["speedup_vs_one_gpu_same_system"] - out["value"] / out["one_gpu_same_system"]) < 1e-9
+    # no RCCL communicator in rehearsal mode, and the line says so
+    assert out["rccl"]["ranks"] is None and "rehearsal" in out["rccl"]["how"]
+
+
+@pytest.mark.gpu
+def test_headline_line_carries_the_sustained_figure_and_untimed_events(device):
+    """The default run's extras: `sustained` measured outside the timed region
+    (dt = 0, here shortened), the force kernel's events taken in a second pass over the same steps."""
+    proc = subprocess.run([sys.executable, BENCH, "--cells-total", "200000", "--steps", "5", "--warmup", "2",
+                           "--sustained-steps", "200", "--no-cpu-baseline", "--no-fast-tier-line"],
+                          capture_output=True, text=True, timeout=900)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    out = json.loads([l for l in proc.stdout.splitlines() if l.strip()][-1])
+    s = out["sustained"]
+    assert s["steps"] == 200 and s["value"] > 0 and s["force_us"] > 0 and s["ms_per_step"] > 0
+    assert s["shader_clock_mhz"]["samples"] >= 1 and 500 < s["shader_clock_mhz"]["median"] < 3000
+    r = out["roofline"]
+    assert r["timed_launches"] == 2 * 5 and "fresh copy" in r["events_pass"]
+    assert r["achieved"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12

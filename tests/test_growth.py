@@ -249,3 +249,17 @@ def test_renumber_moves_links_and_leaves_forces_alone(device):
             runs.append(X)
     assert np.abs(runs[0] - runs[1]).max() <= 1e-5 * np.abs(runs[0]).max()
     assert not np.array_equal(runs[0], np.zeros_like(runs[0]))
+
+
+@pytest.mark.parametrize("model", ["sorting_grid", "push_grid", "clipped_push_grid"])
+def test_models_whose_physics_depend_on_ids_refuse_renumbering_oracle(oracle, model):
+    """sorting (a cell's type is `i < n / 2`) and the push models (the generic force pushes cell 1): new ids
+    would be other physics, so the harness offers renumbering neither every k steps nor on request."""
+    from yalla_amd.solution import Solution, YallaError
+    with Solution(model, 200, 50, 1.0, lib=oracle) as s:
+        s.random_sphere(0.7, 3)
+        before = s.positions().copy()
+        for name in ("renumber_now", "renumber_every"):
+            with pytest.raises(YallaError):
+                s.set_param(name, 1)
+        assert np.array_equal(s.positions(), before)

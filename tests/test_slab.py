@@ -270,6 +270,42 @@ def test_a_failing_rank_takes_the_others_with_it_oracle(oracle):
         s.close()
 
 
+def failing_for_want_of_room(lib, n=3000, world=3):
+    """Slabs whose MIDDLE rank has no room for mirrored cells (n_own + 2 * halo_cap > n_max: -5)."""
+    import ctypes as C
+    X0, _ = reference_run(lib, n, 50, 0.5, 3, 0.001, 0)
+    bounds, halo_cap, mig_cap, n_max = slab_mod.slab_plan(X0, world, 1.0, lib)
+    slabs = []
+    for r in range(world):
+        own = np.flatnonzero((X0[:, 2] >= bounds[r]) & (X0[:, 2] < bounds[r + 1])).astype(np.int32)
+        room = len(own) + 8 if r == 1 else n_max
+        sim = Solution("springs_grid", room, 50, 1.0, lib=lib)
+        sim.h_X[:len(own)] = X0[own]
+        sim.h_n = len(own)
+        sim.copy_to_device()
+        assert lib.ya_slab_init(sim._h, float(bounds[r]), float(bounds[r + 1]), 1.25,
+                                own.ctypes.data_as(C.POINTER(C.c_int))) == 0
+        assert lib.ya_slab_setup(sim._h, r, world, halo_cap, mig_cap) == 0
+        sl = slab_mod.Slab.__new__(slab_mod.Slab)
+        sl.rank, sl.world, sl.sim, sl._lib, sl._h, sl._transport, sl.n_floats = r, world, sim, lib, sim._h, None, 3
+        slabs.append(sl)
+    return slabs
+
+
+def test_a_rank_without_room_for_mirrored_cells_fails_with_the_others_oracle(oracle):
+    """-5: the rank that cannot keep its mirrored cells must go on sending and receiving
+    every stage's rows at the sizes both ends agreed on -- its neighbours did mirror ITS cells -- until
+    the error vote has been summed: all ranks return from the same step, no message has another size
+    than its receiver expects (the in-process transport asserts that), nobody waits for a peer."""
+    slabs = failing_for_want_of_room(oracle)
+    with pytest.raises(slab_mod.YallaError) as raised:
+        slab_mod.run_slabs(slabs, 0.001, 3, migrate_every=1)
+    codes = raised.value.all_codes
+    assert sorted(codes) == [-12, -12, -5], codes   # (in the order the ranks returned)
+    for s in slabs:
+        s.close()
+
+
 def run_ranks(tmp_path, name, port, *worker_args):
     out = tmp_path / name
     env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.path.join(ROOT, "tests"))
@@ -420,10 +456,19 @@ def test_rccl_communicator_single_rank(device):
         # (a real one-rank RCCL communicator from an id, as NativeComm.over_store makes them)
         real = slab_mod.NativeComm.from_id(slab_mod.NativeComm.unique_id(), 0, 1)
         assert (real.rank, real.world) == (0, 1) and real.allreduce_host([3.0], take_max=True) == [3.0]
+        # RCCL's own account of the communicator (ya_comm_info: what bench.py prints as "rccl")
+        facts = real.info()
+        assert facts["kind"] == "rccl" and (facts["ranks"], facts["rank"]) == (1, 0)
+        assert facts["device"] == facts["current_device"] and facts["pci"] > 0
+        assert len(facts["pci_bus_id"].split(":")) == 3
+        gathered = real.gather_info()
+        assert gathered == [{"rank": 0, "ranks": 1, "device": facts["device"], "pci": facts["pci"],
+                             "pci_bus_id": facts["pci_bus_id"].lower()}]
         real.close()
         comm = slab_mod.NativeComm()
         assert (comm.rank, comm.world) == (0, 1)
         assert comm.allreduce_host([1.5, 2.0]) == [1.5, 2.0]
+        assert comm.info()["kind"] == "none"    # world 1 without an id: no RCCL communicator behind it
         X0, Xref = reference_run(device, 20000, 50, 0.5, 3, 0.003, 4)
         sl = slab_mod.Slab("springs_grid", X0, 0, 1, 50, lib=device)
         sl.use(comm=comm)

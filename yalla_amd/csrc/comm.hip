@@ -51,6 +51,9 @@ struct Rccl {
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommCuDevice)(const ncclComm_t, int*) = nullptr;
 };
 
 Rccl* load_rccl();
@@ -102,6 +105,9 @@ Rccl* load_rccl()
     YA_SYM(GroupStart, "ncclGroupStart")
     YA_SYM(GroupEnd, "ncclGroupEnd")
     YA_SYM(GetErrorString, "ncclGetErrorString")
+    YA_SYM(CommCount, "ncclCommCount")
+    YA_SYM(CommUserRank, "ncclCommUserRank")
+    YA_SYM(CommCuDevice, "ncclCommCuDevice")
 #undef YA_SYM
     return &r;
 }
@@ -511,6 +517,32 @@ int ya_comm_destroy(ya_comm* c)
     }
     if (c->d_bounce) (void)hipFree(c->d_bounce);
     delete c;
+    return 0;
+}
+
+int ya_comm_info(const ya_comm* c, int info[8], char pci_bus_id[32])
+{
+    if (!c || !info) return (int)hipErrorInvalidValue;
+    for (int k = 0; k < 8; k++) info[k] = 0;
+    int current = 0;
+    if (hipGetDevice(&current) != hipSuccess) return (int)hipGetLastError();
+    info[0] = c->world, info[1] = c->rank, info[2] = current, info[3] = current;
+    info[4] = c->loop ? 2 : (c->comm ? 1 : 0);
+    if (c->comm) {  // RCCL's own account
+        Rccl* r = rccl();
+        if (!r) return 999;
+        YA_RCCL(r->CommCount(c->comm, &info[0]), "ncclCommCount");
+        YA_RCCL(r->CommUserRank(c->comm, &info[1]), "ncclCommUserRank");
+        YA_RCCL(r->CommCuDevice(c->comm, &info[2]), "ncclCommCuDevice");
+    }
+    char bus[32] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), info[2]) != hipSuccess) return (int)hipGetLastError();
+    unsigned domain = 0, b = 0, d = 0, f = 0;
+    if (sscanf(bus, "%x:%x:%x.%x", &domain, &b, &d, &f) == 4) info[5] = (int)((domain << 16) | (b << 8) | (d << 3) | f);
+    if (pci_bus_id) {
+        strncpy(pci_bus_id, bus, 31);
+        pci_bus_id[31] = 0;
+    }
     return 0;
 }
 

@@ -28,6 +28,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
+#include <unordered_map>
+
 #include "yalla_hip.h"
 
 namespace {
@@ -1475,15 +1478,33 @@ int ya_slab_guard_update(float* d_moved_partial, int n_moved, float* d_pred_part
 int ya_shader_clock_mhz(double microseconds, double* mhz_out)
 {
     if (!mhz_out || !(microseconds > 0) || microseconds > 1e5) return (int)hipErrorInvalidValue;
-    static hipStream_t stream = nullptr;           // of its own, so that it runs BESIDE the work it watches
-    static unsigned long long* h_out = nullptr;    // pinned, written by the kernel itself
-    if (!stream) {
-        YA_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-        YA_TRY(hipHostMalloc((void**)&h_out, 2 * sizeof(unsigned long long), hipHostMallocDefault));
+    // a stream of its own (so that the probe runs BESIDE the work it watches) and a pinned word pair
+    // written by the kernel itself, per device: the probe measures the device that is current for the
+    // CALLING thread (a sampler thread starts on device 0: hipSetDevice first)
+    struct Probe {
+        hipStream_t stream = nullptr;
+        unsigned long long* h_out = nullptr;
+    };
+    static std::mutex lock;
+    static std::unordered_map<int, Probe> probes;
+    int device = 0;
+    YA_TRY(hipGetDevice(&device));
+    std::lock_guard<std::mutex> hold(lock);
+    Probe& p = probes[device];
+    if (!p.stream || !p.h_out) {
+        if (!p.stream) YA_TRY(hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking));
+        if (!p.h_out) {
+            const hipError_t e = hipHostMalloc((void**)&p.h_out, 2 * sizeof(unsigned long long), hipHostMallocDefault);
+            if (e != hipSuccess) {  // nothing half-made is kept for the next call
+                (void)hipStreamDestroy(p.stream);
+                p = Probe{};
+                return (int)e;
+            }
+        }
     }
-    k_shader_clock<<<1, 64, 0, stream>>>((unsigned long long)(microseconds * 100.0), h_out);
-    YA_TRY(hipStreamSynchronize(stream));
-    *mhz_out = h_out[1] ? 100.0 * (double)h_out[0] / (double)h_out[1] : 0.0;
+    k_shader_clock<<<1, 64, 0, p.stream>>>((unsigned long long)(microseconds * 100.0), p.h_out);
+    YA_TRY(hipStreamSynchronize(p.stream));
+    *mhz_out = p.h_out[1] ? 100.0 * (double)p.h_out[0] / (double)p.h_out[1] : 0.0;
     return 0;
 }
 

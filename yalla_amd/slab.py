@@ -79,6 +79,7 @@ class NativeComm:
         lib.ya_comm_rank.argtypes = [C.c_void_p]
         lib.ya_comm_world.argtypes = [C.c_void_p]
         lib.ya_comm_allreduce_host.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int]
+        lib.ya_comm_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_char_p]
         return lib
 
     @classmethod
@@ -136,6 +137,34 @@ class NativeComm:
 
     def barrier(self):
         self.allreduce_host([0.0])
+
+    def info(self):
+        """What RCCL itself says about this communicator (ya_comm_info: ncclCommCount, ncclCommUserRank,
+        ncclCommCuDevice) and where that device sits on the PCI bus."""
+        raw = (C.c_int * 8)()
+        bus = C.create_string_buffer(32)
+        code = self._lib.ya_comm_info(self.handle, raw, bus)
+        if code != 0:
+            raise YallaError(f"ya_comm_info failed ({code})")
+        return {"ranks": raw[0], "rank": raw[1], "device": raw[2], "current_device": raw[3],
+                "kind": {0: "none", 1: "rccl", 2: "loopback"}[raw[4]], "pci": raw[5], "pci_bus_id": bus.value.decode()}
+
+    def gather_info(self):
+        """info() of every rank, gathered over the communicator itself (each rank fills its own slots
+        of a host all-reduce): [{rank, ranks, device, pci, pci_bus_id}, ...] in rank order, the same on
+        every rank.  Raises if the ranks disagree about the communicator's size."""
+        mine = self.info()
+        assert self.world * 4 <= 64, "ya_comm_allreduce_host carries 64 values"
+        slots = [0.0] * (4 * self.world)
+        slots[4 * self.rank: 4 * self.rank + 4] = [float(mine["ranks"]), float(mine["rank"]),
+                                                   float(mine["device"]), float(mine["pci"])]
+        slots = self.allreduce_host(slots)
+        out = []
+        for r in range(self.world):
+            ranks, rank, device, pci = (int(v) for v in slots[4 * r: 4 * r + 4])
+            out.append({"rank": rank, "ranks": ranks, "device": device, "pci": pci,
+                        "pci_bus_id": "%04x:%02x:%02x.%x" % (pci >> 16, (pci >> 8) & 0xff, (pci >> 3) & 0x1f, pci & 7)})
+        return out
 
     def close(self):
         if self.handle:
