@@ -1571,6 +1571,104 @@ __global__ __launch_bounds__(ya::UPDATE_BLOCK) void ghosts_into_sorted(const int
     if (id >= n_active) d_sorted[s].X = d_X1[id];
 }
 
+// Round 5: the update kernels of the sorted-space step fold the reduction's partial sums THEMSELVES.
+// ya_reduce_mean was two launches -- B per-block partial sums, then one workgroup that folds them
+// and scales by 1 / n -- and the second one is a whole launch (4-5 us, four times per step at any
+// system size) for a few hundred additions.  Every workgroup of the kernel that needs the mean now
+// repeats that fold from the partials (<= 1024 x 3 floats, L2 hits): the same additions in the same
+// tree (lane t takes partials t, t + 256, ...; lanes folded by halving), the same `sum * float(1. / n)`
+// (dtypes.cuh:202-217), hence the same bits as ya_reduce_mean leaves in d_mean -- only x, y, z, all the
+// update kernels subtract (solvers.cuh:113-144).
+namespace ya {
+template<int NF>
+__device__ __forceinline__ float3 fixed_velocity_from_partials(const float* __restrict__ partials, const int n_partials,
+    const int n)
+{
+    static_assert(UPDATE_BLOCK == 256, "the fold is libyalla_hip.so's fold256");
+    __shared__ float sh[3 * UPDATE_BLOCK];
+    float acc[3] = {0.f, 0.f, 0.f};
+    for (int p = threadIdx.x; p < n_partials; p += UPDATE_BLOCK) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) acc[k] = acc[k] + partials[(size_t)p * NF + k];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) sh[k * UPDATE_BLOCK + threadIdx.x] = acc[k];
+    __syncthreads();
+    if ((int)threadIdx.x < 128) {
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+            sh[k * UPDATE_BLOCK + threadIdx.x] = sh[k * UPDATE_BLOCK + threadIdx.x] + sh[k * UPDATE_BLOCK + threadIdx.x + 128];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < 64) {
+        float v[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) v[k] = sh[k * UPDATE_BLOCK + threadIdx.x] + sh[k * UPDATE_BLOCK + threadIdx.x + 64];
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) v[k] = v[k] + __shfl_down(v[k], s, 64);
+        }
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) sh[k * UPDATE_BLOCK] = v[k];
+        }
+    }
+    __syncthreads();
+    const float inv = (float)(1. / (double)(float)n);  // Pt / n == Pt * float(1. / float(n))
+    return float3{sh[0] * inv, sh[UPDATE_BLOCK] * inv, sh[2 * UPDATE_BLOCK] * inv};
+}
+}  // namespace ya
+
+// euler_step_sorted with the fixed velocity = the mean of the stage's right-hand sides, folded here from
+// the reduction's partial sums; workgroup 0 leaves it in d_fix_out for the corrector.
+template<typename Pt>
+__global__ __launch_bounds__(ya::UPDATE_BLOCK) void euler_step_sorted_folding(const int n, const float dt,
+    const float* __restrict__ partials, const int n_partials, float* __restrict__ d_fix_out,
+    const Pt* __restrict__ d_dX_sorted, ya::Entry<Pt>* __restrict__ d_sorted)
+{
+    const float3 fix = ya::fixed_velocity_from_partials<ya::N_floats<Pt>::value>(partials, n_partials, n);
+    const int s = blockIdx.x * ya::UPDATE_BLOCK + threadIdx.x;
+    if (s == 0) {
+        d_fix_out[0] = fix.x;
+        d_fix_out[1] = fix.y;
+        d_fix_out[2] = fix.z;
+    }
+    if (s >= n) return;
+    Pt dX = d_dX_sorted[s];
+    dX.x -= fix.x;
+    dX.y -= fix.y;
+    dX.z -= fix.z;
+    ya::Entry<Pt> e = d_sorted[s];
+    e.X = e.X + dX * dt;
+    d_sorted[s] = e;
+}
+
+// heun_step_raw with the second stage's fixed velocity folded from its partial sums.
+template<typename Pt>
+__global__ __launch_bounds__(ya::UPDATE_BLOCK) void heun_step_raw_folding(const int n, const float dt,
+    const Pt* __restrict__ d_dX, const float* __restrict__ d_fix, const Pt* __restrict__ d_dX1,
+    const float* __restrict__ partials1, const int n_partials1, Pt* __restrict__ d_X, float3* __restrict__ d_old_v)
+{
+    const float3 fix1 = ya::fixed_velocity_from_partials<ya::N_floats<Pt>::value>(partials1, n_partials1, n);
+    const int i = blockIdx.x * ya::UPDATE_BLOCK + threadIdx.x;
+    if (i >= n) return;
+
+    Pt dX = d_dX[i];
+    dX.x -= d_fix[0];
+    dX.y -= d_fix[1];
+    dX.z -= d_fix[2];
+    Pt dX1 = d_dX1[i];
+    dX1.x -= fix1.x;
+    dX1.y -= fix1.y;
+    dX1.z -= fix1.z;
+    Pt X = d_X[i];
+    X += (dX + dX1) * 0.5 * dt;
+    d_X[i] = X;
+    d_old_v[i] = float3{
+        (dX.x + dX1.x) * 0.5f, (dX.y + dX1.y) * 0.5f, (dX.z + dX1.z) * 0.5f};
+}
+
 template<typename Pt>
 __global__ __launch_bounds__(ya::UPDATE_BLOCK) void heun_step_raw(const int n, const float dt,
     const Pt* __restrict__ d_dX, const float* __restrict__ d_fix, const Pt* __restrict__ d_dX1,
@@ -1772,6 +1870,22 @@ public:
 };
 
 
+// The three-parameter spelling `Solution<Pt, n_max, Solver>` of older ya||a model files (and of this
+// build's north_star): the capacity as a template argument, objects default-constructed.  C++ cannot
+// overload a class template on the KIND of its parameters, so beside the reference's two-parameter
+// `Solution<Pt, Solver>{n_max, ...}` (every example at the surveyed commit) it has a name of its own:
+//     Solution_n<float3, 800, Tile_solver> bodies;            // = Solution<float3, Tile_solver>{800}
+//     Solution_n<float3, 100000, Grid_solver> cells{64, 1.f}; // solver arguments follow as usual
+template<typename Pt, int N_MAX, template<typename> class Solver>
+class Solution_n : public Solution<Pt, Solver> {
+public:
+    static constexpr int capacity = N_MAX;
+    template<typename... Args>
+    Solution_n(Args... args) : Solution<Pt, Solver>{N_MAX, args...}
+    {}
+};
+
+
 // Two-stage Heun integrator (solvers.cuh:164-276).  Computer specifies how
 // pairwise interactions are computed.
 template<typename Pt, template<typename> class Computer>
@@ -1895,6 +2009,9 @@ protected:
     bool mirrored_in_sorted_copy = false;  // ... and the mirrored cells' predictor is in it already
     bool fix_com = true;
     bool fix_com_z = false;
+    // sorted-space step with set_fixed(): the update kernels fold the reductions' partial sums themselves
+    // (ya::fixed_velocity_from_partials; false = ya_reduce_mean's second launch, A/B)
+    bool fold_in_update = true;
     int fix_point = 0;
     const int n_max;
     int get_d_n()
@@ -2067,6 +2184,18 @@ protected:
     {
         const int blocks = (n + ya::UPDATE_BLOCK - 1) / ya::UPDATE_BLOCK;
         Computer<Pt>::template pwints<pw_int, pw_friction>(n, d_X, d_old_v, d_dX, false, n, true);
+        if (fix_com and !fix_com_z and fold_in_update) {
+            // set_fixed() (the default): both fixed velocities are means, folded by the update kernels
+            // themselves from the reductions' partial sums (two launches fewer; same bits)
+            int n_partials = 0;
+            YA_CHECK(ya_reduce_partials(d_dX, n_floats, n, d_workspace, &n_partials, this->stream));
+            Computer<Pt>::predictor_in_sorted_space_folding(n, dt, d_workspace, n_partials, d_mean_first);
+            Computer<Pt>::template pwints_from_sorted<pw_int, pw_friction>(n, d_dX1, n, false);
+            YA_CHECK(ya_reduce_partials(d_dX1, n_floats, n, d_workspace, &n_partials, this->stream));
+            heun_step_raw_folding<<<blocks, ya::UPDATE_BLOCK, 0, this->stream>>>(
+                n, dt, d_dX, d_mean_first, d_dX1, d_workspace, n_partials, d_X, d_old_v);
+            return;
+        }
         // this stage's fixed velocity has to outlive the next reduction
         const float* fix = fix_velocity(n, d_dX, fix_com or fix_com_z, fix_com_z, true);
         Computer<Pt>::predictor_in_sorted_space(n, dt, fix, n);
@@ -2190,6 +2319,7 @@ protected:
     const int* cube_order(int, const Pt*) { return nullptr; }  // no grid: renumber() is a no-op
     void ids_changed() {}
     void predictor_in_sorted_space(int, float, const float*, int) {}
+    void predictor_in_sorted_space_folding(int, float, const float*, int, float*) {}
     void predictor_in_sorted_space_mirrored(int, float, const float*, float*, int, const Pt*, int, float*, ya::Guard_band) {}
     void ghosts_in_sorted_space(int, int, const Pt*) {}
     template<Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction>
@@ -2574,6 +2704,12 @@ protected:
     {
         euler_step_sorted<<<(n + ya::UPDATE_BLOCK - 1) / ya::UPDATE_BLOCK, ya::UPDATE_BLOCK, 0, stream>>>(
             n, dt, d_fix, d_dX_sorted, d_sorted, n_active);
+    }
+    void predictor_in_sorted_space_folding(const int n, const float dt, const float* d_partials, const int n_partials,
+        float* d_fix_out)
+    {
+        euler_step_sorted_folding<<<(n + ya::UPDATE_BLOCK - 1) / ya::UPDATE_BLOCK, ya::UPDATE_BLOCK, 0, stream>>>(
+            n, dt, d_partials, n_partials, d_fix_out, d_dX_sorted, d_sorted);
     }
     void predictor_in_sorted_space_mirrored(const int n, const float dt, const float* d_total, float* d_fix_out,
         const int n_active, const Pt* d_dX, const int fix_mode, float* pred_partial, const ya::Guard_band band)

@@ -29,7 +29,7 @@ extern "C" {
 /* The libraries are built with -fvisibility=hidden; only this C ABI is exported. */
 #pragma GCC visibility push(default)
 
-#define YA_ABI_VERSION 9  /* 9: + ya_comm_info; 8: + ya_grid_set_cube_range, YA_STATUS_OUT_OF_RANGE, the slab guard / fixed point / payload entries, ya_async_read_* */
+#define YA_ABI_VERSION 9  /* 9: + ya_comm_info, ya_reduce_partials; 8: + ya_grid_set_cube_range, YA_STATUS_OUT_OF_RANGE, the slab guard / fixed point / payload entries, ya_async_read_* */
 
 /* Status bits reported by ya_grid_status(). */
 #define YA_STATUS_OUT_OF_GRID 1 /* a cell's cube id fell outside [0, n_cubes):
@@ -185,6 +185,11 @@ int ya_reduce_mean(const void* d_v, int n_floats, int n, float* d_out,
 int ya_reduce_sum_packed(const void* d_v, int n_floats, int n, float* d_out, float* d_workspace,
     void* stream);
 
+/* The first half of ya_reduce_mean alone: the B = clamp(ceil(n / 256), 1, 1024) per-block partial sums
+ * {sum[n_floats]} left in d_workspace, *n_partials = B.  For update kernels that fold the partials
+ * themselves (include/solvers.cuh, ya::fixed_velocity_from_partials: the same tree, the same bits as
+ * ya_reduce_mean's second launch, which they replace). */
+int ya_reduce_partials(const void* d_v, int n_floats, int n, float* d_workspace, int* n_partials, void* stream);
 /* Size in bytes of the workspace ya_reduce_mean needs. */
 size_t ya_reduce_workspace_bytes(int n_floats);
 

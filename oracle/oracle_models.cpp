@@ -188,3 +188,44 @@ using harness_ops = Oracle_slab_ops;
 
 
 #include "models_harness.inc"
+
+
+// ---- pair trace (oracle/yalla_host.hpp, Pair_trace): diagnostics for tools/diag/slab_case.py ----------------
+// Only the oracle library exports these; nothing in include/ declares them.
+extern "C" {
+__attribute__((visibility("default"))) int ya_oracle_trace_begin(const int* ids, int n_ids, float margin)
+{
+    if (!ids || n_ids < 0) return -3;
+    Pair_trace& t = pair_trace();
+    std::lock_guard<std::mutex> hold(t.lock);
+    t.ids.assign(ids, ids + n_ids);
+    std::sort(t.ids.begin(), t.ids.end());
+    t.margin = margin;
+    t.recs.clear();
+    t.armed.store(true);
+    return 0;
+}
+// rows of {call, i, j, dist as bits}; returns how many records there are (read again with more room if > cap)
+__attribute__((visibility("default"))) int ya_oracle_trace_read(int* rows, int cap)
+{
+    Pair_trace& t = pair_trace();
+    std::lock_guard<std::mutex> hold(t.lock);
+    const int n = (int)t.recs.size();
+    for (int k = 0; k < n && k < cap && rows; k++) {
+        rows[4 * k + 0] = t.recs[k].call;
+        rows[4 * k + 1] = t.recs[k].i;
+        rows[4 * k + 2] = t.recs[k].j;
+        memcpy(&rows[4 * k + 3], &t.recs[k].dist, sizeof(float));
+    }
+    return n;
+}
+__attribute__((visibility("default"))) int ya_oracle_trace_end(void)
+{
+    Pair_trace& t = pair_trace();
+    std::lock_guard<std::mutex> hold(t.lock);
+    t.armed.store(false);
+    t.recs.clear();
+    t.ids.clear();
+    return 0;
+}
+}

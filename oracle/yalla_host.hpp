@@ -34,7 +34,9 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <functional>
+#include <mutex>
 #include <type_traits>
 #include <vector>
 
@@ -411,6 +413,36 @@ public:
 
 static int d_nhood[27];  // solvers.cuh:428
 
+// ---- pair trace (diagnostics, not in the reference) ----------------------------------------------------
+// For a handful of cells (by the id the functor sees: the global id in a z-slab decomposition) every
+// candidate pair whose distance is below cube_size + margin is written down with the number of the
+// pwints call it was tested in (a solver's calls count from 0: step k's two stages are calls 2k - 2 and
+// 2k - 1) -- so that two runs of one system (undivided / in slabs) can be compared pair by pair where a
+// cell's position first differs: tools/diag/slab_case.py.  Off unless armed (oracle_models.cpp:
+// ya_oracle_trace_*); several slabs' host threads may record at once.
+struct Pair_trace {
+    struct Rec {
+        int call, i, j;
+        float dist;
+    };
+    std::mutex lock;
+    std::vector<int> ids;  // sorted
+    float margin = 0.f;
+    std::vector<Rec> recs;
+    std::atomic<bool> armed{false};
+    bool wants(int id) const { return std::binary_search(ids.begin(), ids.end(), id); }
+    void add(int call, int i, int j, float dist)
+    {
+        std::lock_guard<std::mutex> hold(lock);
+        recs.push_back(Rec{call, i, j, dist});
+    }
+};
+inline Pair_trace& pair_trace()
+{
+    static Pair_trace t;
+    return t;
+}
+
 // Grid_computer: solvers.cuh:430-502
 template<typename Pt>
 class Grid_computer {
@@ -437,6 +469,7 @@ public:
     Grid grid;  // public in the oracle so tests can read the four arrays
     // z-slab decomposition (not in the reference): local index -> global id for the functors
     const int* d_global_id = nullptr;
+    int pwints_calls = 0;  // (pair trace: which call a pair was tested in)
 
 protected:
     int nhood[27];
@@ -452,9 +485,13 @@ protected:
     {
         if (n_active < 0) n_active = n;
         grid.build(n, d_X, cube_size);  // :494
+        Pair_trace& trace = pair_trace();
+        const bool tracing = trace.armed.load();
+        const int call = pwints_calls++;
         for (int i = 0; i < n; i++) {   // thread i owns sorted slot i: :430-463
             int pi = grid.d_point_id[i];
             if (pi >= n_active) continue;  // ghost cell of a slab decomposition (not in the reference)
+            const bool traced = tracing && trace.wants(d_global_id ? d_global_id[pi] : pi);
             Pt Xi = d_X[pi];
             Pt F;
             memset(&F, 0, sizeof(Pt));
@@ -469,6 +506,8 @@ protected:
                     int pk = grid.d_point_id[k];
                     Pt r = Xi - d_X[pk];
                     float dist = ya_dist3(r.x, r.y, r.z);
+                    if (traced && dist < cube_size + trace.margin)
+                        trace.add(call, d_global_id ? d_global_id[pi] : pi, d_global_id ? d_global_id[pk] : pk, dist);
                     if (dist >= cube_size) continue;  // :450
                     const int gi = d_global_id ? d_global_id[pi] : pi;
                     const int gk = d_global_id ? d_global_id[pk] : pk;
@@ -743,6 +782,16 @@ public:
     {
         return Solver<Pt>::template take_step<pw_int, pw_friction>(dt, gen_forces);
     }
+};
+
+// Solution<Pt, n_max, Solver> under the name the engine's headers give it (include/solvers.cuh).
+template<typename Pt, int N_MAX, template<typename> class Solver>
+class Solution_n : public Solution<Pt, Solver> {
+public:
+    static constexpr int capacity = N_MAX;
+    template<typename... Args>
+    Solution_n(Args... args) : Solution<Pt, Solver>{N_MAX, args...}
+    {}
 };
 
 // ---------------------------------------------------------------------------

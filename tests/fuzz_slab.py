@@ -7,20 +7,24 @@ of cells; for every third case, which runs fading_grid (a force that fades to ze
 friction_on_background: yalla_amd/csrc/model_functors.h) over three times the steps: 2e-6 for EVERY cell.  The
 COM sum is reassociated across slabs (1e-7 relative per step), and the spring force of the
 benchmark model is cut off at cube_size where it is NOT zero: a pair within rounding of the
-cut-off interacts in one run and not in the other, which moves two cells by 0.5 dt at once
-(about two such pairs per step per 40 000 cells) -- those cells are counted, not tolerated
-silently, against a budget that follows that rate: four cells per step per 40 000 cells (a pair's
-two cells; two steps later their neighbours follow at 1e-4 through friction_w_neighbour, which
-averages the neighbours' velocities: seed 90007, 12 steps of 28 005 cells, 4 pairs and 11 of their
-neighbours, looked at step by step with tools/diag/slab_case.py -- the first cell differs after step
-10, none of the pairs sits nearer a cut than elsewhere).  A decomposition that loses cells'
-neighbours is off for every cell along a cut at once, hundreds of cells in the first step.  Slabs
+cut-off interacts in one run and not in the other, which moves two cells by 0.5 dt at once; two
+steps later the cells that average those two cells' velocities follow at 1e-4.  Such cells are not
+tolerated on a rate (round 4 did: four per step per 40 000 cells): every case that leaves a cell
+beyond 1e-5 is run again on the oracle backend with its pair trace (tests/slab_explain.py), which
+names for every divergent cell the partner that sits at dist < cube_size in one run and >= in the
+other, with both distances (seed 90007: 4 pairs at 1.0 against 0.99999988 in stage 2, 11
+followers of them -- profiles/r05_fuzz_slab_case_90007.txt), or the earlier-divergent partner it
+follows.  A cell the oracle run cannot explain that way fails the case (a decomposition that
+loses cells' neighbours is off for every cell along a cut at once, hundreds in the first step,
+none of them with a partner at the cut-off); device cells outside the oracle's explained set
+count against the old small budget max(4, n / 2000).  Slabs
 thinner than the ghost layer (tiny systems in many slabs) are skipped: a cell's neighbours would
 sit two slabs away."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
+import slab_explain
 import test_slab
 from yalla_amd import _ffi
 
@@ -28,6 +32,7 @@ if __name__ == "__main__":
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 100
     device = _ffi.device_lib()
+    oracle = _ffi.bind(os.path.join(ROOT, "oracle", "_build", "liboracle_models.so"))
     bad = 0
     for seed in range(first, first + cases):
         rng = np.random.default_rng(seed)
@@ -52,12 +57,22 @@ if __name__ == "__main__":
         diff = np.abs(X - Xref).max(axis=1)
         scale = np.abs(Xref).max()
         off = int((diff > 1e-5 * scale).sum())
+        note = ""
         if strict:
             ok = diff.max() <= 2e-6 * scale
+        elif off == 0:
+            ok = True
         else:
-            ok = off <= max(4, n // 2000, int(4 * steps * n / 40000)) and diff.max() <= 2.0 * steps * dt
+            # every divergent cell must have its reason: the same case on the oracle, pair by pair
+            report = slab_explain.explain(oracle, n, world, steps, dt, every, model=model)
+            explained = {f["cell"] for f in report["flips"]} | {f["cell"] for f in report["followers"]}
+            elsewhere = [int(i) for i in np.nonzero(diff > 1e-5 * scale)[0] if int(i) not in explained]
+            pairs = {tuple(sorted((f["cell"], p["partner"]))) for f in report["flips"] for p in f["pairs"]}
+            ok = (not report["unexplained"] and len(elsewhere) <= max(4, n // 2000) and diff.max() <= 2.0 * steps * dt)
+            note = " explained on the oracle: %d pairs at the cut-off, %d followers, %d unexplained; device cells outside that set: %d" % (
+                len(pairs), len(report["followers"]), len(report["unexplained"]), len(elsewhere))
         bad += not ok
         print("ok  " if ok else "FAIL", case, "moved", moved, "cells beyond 1e-5:", off,
-              "max diff %.2e" % diff.max(), flush=True)
+              "max diff %.2e" % diff.max() + note, flush=True)
     print(f"{cases - bad} of {cases} slab cases within 1e-5 of the undivided system")
     sys.exit(1 if bad else 0)

@@ -74,6 +74,14 @@ def test_one_line_declares_a_functor_stateless():
 
 
 @pytest.mark.gpu
+def test_three_parameter_solution_spelling():
+    """Solution_n<Pt, n_max, Solver> (north_star's `Solution<Pt, n_max, Solver>`; a class template
+    cannot be overloaded on the kind of its parameters, hence the name): default-constructed with the capacity
+    as a template argument, the same object and the same steps as Solution<Pt, Solver>{n_max, ...}."""
+    run("test_solution_n", "ALL SOLUTION_N TESTS PASSED")
+
+
+@pytest.mark.gpu
 def test_force_launch_trace(tmp_path):
     """tools/micro/force_trace.hip (the force kernel built with -DYA_BITS_TRACE: every workgroup
     stamps its start, end, CU and XCD) through tools/force_trace_summary.py: one workgroup per

@@ -77,7 +77,7 @@ CORE_ABI = [
     "ya_gather_rows_pair",
     "ya_append_rows", "ya_comm_unique_id", "ya_comm_create", "ya_comm_create_loopback", "ya_comm_create_from_env",
     "ya_comm_destroy", "ya_comm_rank", "ya_comm_world", "ya_comm_exchange", "ya_comm_exchange_v",
-    "ya_comm_allreduce_sum", "ya_comm_allreduce_host", "ya_comm_self_exchange", "ya_comm_info",
+    "ya_comm_allreduce_sum", "ya_comm_allreduce_host", "ya_comm_self_exchange", "ya_comm_info", "ya_reduce_partials",
     "ya_shader_clock_mhz", "ya_grid_set_cube_range", "ya_grid_forget_order", "ya_copy_component", "ya_pack_cells", "ya_append_cells", "ya_fill_holes", "ya_find_id", "ya_max_abs_diff", "ya_max_abs_diff_partials",
     "ya_slab_guard_update", "ya_slab_pack", "ya_async_read_create", "ya_async_read_destroy",
     "ya_async_read_begin", "ya_async_read_end", "ya_async_read_target", "ya_async_read_mark",

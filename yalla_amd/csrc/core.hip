@@ -21,6 +21,12 @@
 //              optionally gathers {X, id} and old_v into sorted order so the
 //              force kernel streams them.
 //
+// (Round 5 built the four kernels as the four phases of ONE 1024-thread workgroup for systems of <= 16 k
+// cells in <= 32 k cubes -- a step of such a system is bound by its ~14 dependent launches at ~5 us each --
+// bit-identical and SLOWER: examples/sorting.cu at 10 k cells 79 -> 141 us per step.  One CU cannot keep
+// enough loads in flight: ten cells per thread and phase, each a dependent round trip to the L2, where the
+// kernels spread over 40 CUs.  profiles/r05_nonforce_ab.jsonl, tools/micro/r05_small_build.patch.)
+//
 // Everything is int32/fp32; compile with -ffp-contract=off so the cube id
 // arithmetic is the plain IEEE evaluation the oracle restates.
 #include <hip/hip_runtime.h>
@@ -320,18 +326,34 @@ __global__ __launch_bounds__(BLOCK) void k_order_from(const int* __restrict__ ar
 template<int NW>
 __device__ __forceinline__ void fold256(float (&acc)[NW], float* sh /* [NW][256] */)
 {
+    // lane[t] += lane[t + s] for s = 128 ... 1 (the documented order).  Round 5: from s = 32 down the
+    // operands sit in ONE wavefront and travel by shuffle instead of through LDS and a workgroup
+    // barrier per step -- the same additions of the same operands, so the same bits: a reduction
+    // kernel is 8 barriers shorter (4.9 -> 3.4 us per launch at any size).
 #pragma unroll
     for (int k = 0; k < NW; k++) sh[k * BLOCK + threadIdx.x] = acc[k];
     __syncthreads();
-    for (int s = BLOCK / 2; s >= 1; s >>= 1) {
-        if ((int)threadIdx.x < s) {
+    if ((int)threadIdx.x < 128) {
 #pragma unroll
-            for (int k = 0; k < NW; k++)
-                sh[k * BLOCK + threadIdx.x] =
-                    sh[k * BLOCK + threadIdx.x] + sh[k * BLOCK + threadIdx.x + s];
-        }
-        __syncthreads();
+        for (int k = 0; k < NW; k++)
+            sh[k * BLOCK + threadIdx.x] = sh[k * BLOCK + threadIdx.x] + sh[k * BLOCK + threadIdx.x + 128];
     }
+    __syncthreads();
+    if ((int)threadIdx.x < 64) {
+        float v[NW];
+#pragma unroll
+        for (int k = 0; k < NW; k++) v[k] = sh[k * BLOCK + threadIdx.x] + sh[k * BLOCK + threadIdx.x + 64];
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) {
+#pragma unroll
+            for (int k = 0; k < NW; k++) v[k] = v[k] + __shfl_down(v[k], s, 64);
+        }
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int k = 0; k < NW; k++) sh[k * BLOCK] = v[k];
+        }
+    }
+    __syncthreads();
 }
 
 // (Round 5 tried ONE launch -- the block that draws the last ticket folds the partials, same order --
@@ -747,6 +769,16 @@ int launch_reduce(const float* v, int n, float* out, float* ws, hipStream_t st, 
     else
         k_reduce_final<NW><<<1, BLOCK, 0, st>>>(ws, B, n, out);
     return (int)hipGetLastError();
+}
+
+template<int NW>
+int launch_partials(const float* v, int n, float* ws, hipStream_t st)
+{
+    int B = ceil_div(n, BLOCK);
+    if (B < 1) B = 1;
+    if (B > REDUCE_MAX_BLOCKS) B = REDUCE_MAX_BLOCKS;
+    k_reduce_partial<NW><<<B, BLOCK, 0, st>>>(v, n, ws);
+    return B;
 }
 
 struct Pack_extra {
@@ -1304,6 +1336,37 @@ static int reduce_any(const void* d_v, int n_floats, int n, float* d_out, float*
         default:
             return (int)hipErrorInvalidValue;
     }
+}
+
+int ya_reduce_partials(const void* d_v, int n_floats, int n, float* d_ws, int* n_partials, void* stream)
+{
+    if (!d_v || !d_ws || !n_partials || n < 0) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    const float* v = (const float*)d_v;
+    switch (n_floats) {
+#define YA_RED(NW)                                      \
+    case NW:                                            \
+        *n_partials = launch_partials<NW>(v, n, d_ws, st); \
+        break;
+        YA_RED(3)
+        YA_RED(4)
+        YA_RED(5)
+        YA_RED(6)
+        YA_RED(7)
+        YA_RED(8)
+        YA_RED(9)
+        YA_RED(10)
+        YA_RED(11)
+        YA_RED(12)
+        YA_RED(13)
+        YA_RED(14)
+        YA_RED(15)
+        YA_RED(16)
+#undef YA_RED
+        default:
+            return (int)hipErrorInvalidValue;
+    }
+    return (int)hipGetLastError();
 }
 
 int ya_reduce_mean(const void* d_v, int n_floats, int n, float* d_out, float* d_ws, void* stream)
