@@ -1964,6 +1964,23 @@ public:
         last_key = Step_key{};
     }
 
+    // ... or ONE line after the model has made its arrays, instead of a call in its loop (round 5):
+    //     cells.keep_in_cube_order(10, type, n_mes_nbs, n_epi_nbs, links, d_state);
+    // -- every `every`-th take_step (the next one first) begins with renumber(arrays...).  The arrays are
+    // taken by reference: they must outlive the solver's steps, as they must in a loop that calls
+    // renumber itself.  every <= 0 switches it off again.  Cells a model kernel appended since the last
+    // renumbering (proliferation) are put in their places by the next one.
+    template<typename... Arrays>
+    void keep_in_cube_order(const int every, Arrays&... arrays)
+    {
+        keep_order_every = every;
+        keep_order_wait = 0;
+        if (every > 0)
+            keep_order = [this, &arrays...]() { this->renumber(arrays...); };
+        else
+            keep_order = nullptr;
+    }
+
     // Replaying the step as one hipGraph (Grid_solver without generic forces), opt-in:
     // 1 = whenever possible, -1 = for systems below YA_GRAPH_MAX_CELLS cells, 0 (default) =
     // never.  The graph is captured the second time the same step (functors, n, dt, fixed
@@ -2007,6 +2024,8 @@ protected:
     ya_n_reader* n_reader = nullptr;
     int sorted_stage_cells = -1;  // stage API: cells in the sorted copy stage 2 may start from
     bool mirrored_in_sorted_copy = false;  // ... and the mirrored cells' predictor is in it already
+    std::function<void()> keep_order;  // keep_in_cube_order: renumber(the registered arrays)
+    int keep_order_every = 0, keep_order_wait = 0;
     bool fix_com = true;
     bool fix_com_z = false;
     // sorted-space step with set_fixed(): the update kernels fold the reductions' partial sums themselves
@@ -2223,6 +2242,10 @@ protected:
     template<Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction>
     void take_step(float dt, Generic_forces<Pt> gen_forces)
     {
+        if (keep_order && keep_order_wait-- <= 0) {  // keep_in_cube_order
+            keep_order();
+            keep_order_wait = keep_order_every - 1;
+        }
         const bool sorted_path =
             Computer<Pt>::use_sorted_pipeline() && ya::is_no_gen_forces<Pt>(gen_forces);
         int n;

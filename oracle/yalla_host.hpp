@@ -580,6 +580,21 @@ public:
         (void)unused;
     }
 
+    // ... registered once (include/solvers.cuh, keep_in_cube_order): every `every`-th take_step, the next
+    // one first, begins with renumber(arrays...)
+    template<typename... Arrays>
+    void keep_in_cube_order(const int every, Arrays&... arrays)
+    {
+        keep_order_every = every;
+        keep_order_wait = 0;
+        if (every > 0)
+            keep_order = [this, &arrays...]() { this->renumber(arrays...); };
+        else
+            keep_order = nullptr;
+    }
+    std::function<void()> keep_order;
+    int keep_order_every = 0, keep_order_wait = 0;
+
 protected:
     template<typename T>
     static void permute_array(const std::vector<int>& order, T* array)
@@ -676,6 +691,10 @@ protected:
     template<Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction>
     void take_step(float dt, Generic_forces<Pt> gen_forces)
     {
+        if (keep_order && keep_order_wait-- <= 0) {  // keep_in_cube_order (not in the reference)
+            keep_order();
+            keep_order_wait = keep_order_every - 1;
+        }
         int n = get_d_n();  // :229
 
         // 1st stage, :231-255

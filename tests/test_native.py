@@ -82,6 +82,14 @@ def test_three_parameter_solution_spelling():
 
 
 @pytest.mark.gpu
+def test_arrays_registered_once_are_kept_in_cube_order():
+    """Solution::keep_in_cube_order(every, arrays...) (VERDICT r04 item 6): one line in the model instead of a
+    renumber call in its loop -- a Property read by id inside the functor, Links, a plain device array and
+    cells appended between steps: bit for bit what renumbering by hand every third step gives."""
+    run("test_keep_order", "ALL KEEP-ORDER TESTS PASSED")
+
+
+@pytest.mark.gpu
 def test_force_launch_trace(tmp_path):
     """tools/micro/force_trace.hip (the force kernel built with -DYA_BITS_TRACE: every workgroup
     stamps its start, end, CU and XCD) through tools/force_trace_summary.py: one workgroup per
