@@ -36,6 +36,52 @@ __global__ void k_slab_mean_from_total(const float* total, int n_floats, float* 
 }
 // Backend operations of the slab logic on the device: thin wrappers over the C ABI.
 struct Slab_device_ops {
+    static constexpr bool device = true;
+    using Stream = hipStream_t;
+    using Guard_band = ya::Guard_band;
+    static constexpr int guard_slots = ya::GUARD_SLOTS;
+    template<typename Pt>
+    static bool has_generic_forces(const Generic_forces<Pt>& gen) { return !ya::is_no_gen_forces<Pt>(gen); }
+    // a stage's rows over RCCL: on a stream of their own between two events -- they leave once the packed
+    // rows are complete (the step's stream has reached `packed`), the update waits for `landed` (rows_wait),
+    // the interior launch runs meanwhile
+    static int rows_over_rccl(void* rccl, void*& stream, void*& packed, void*& landed, const void* send_lo, size_t out_lo,
+        void* recv_lo, size_t in_lo, const void* send_hi, size_t out_hi, void* recv_hi, size_t in_hi)
+    {
+        if (!stream) {
+            hipStream_t st;
+            hipEvent_t a, b;
+            YA_CHECK((int)hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+            YA_CHECK((int)hipEventCreateWithFlags(&a, hipEventDisableTiming));
+            YA_CHECK((int)hipEventCreateWithFlags(&b, hipEventDisableTiming));
+            stream = st;
+            packed = a;
+            landed = b;
+        }
+        YA_CHECK((int)hipEventRecord((hipEvent_t)packed, nullptr));
+        YA_CHECK((int)hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)packed, 0));
+        const int rc = ya_comm_exchange_v((ya_comm*)rccl, send_lo, out_lo, recv_lo, in_lo, send_hi, out_hi, recv_hi, in_hi,
+            stream);
+        YA_CHECK((int)hipEventRecord((hipEvent_t)landed, (hipStream_t)stream));
+        return rc;
+    }
+    static void rows_wait(void* landed) { YA_CHECK((int)hipStreamWaitEvent(nullptr, (hipEvent_t)landed, 0)); }
+    static void rows_path_destroy(void* stream, void* packed, void* landed)
+    {
+        if (!stream) return;
+        (void)hipStreamDestroy((hipStream_t)stream);
+        (void)hipEventDestroy((hipEvent_t)packed);
+        (void)hipEventDestroy((hipEvent_t)landed);
+    }
+    static int rccl_is(void* comm, int rank, int world)
+    {
+        return comm && ya_comm_rank((ya_comm*)comm) == rank && ya_comm_world((ya_comm*)comm) == world ? 0 : -3;
+    }
+    static int rccl_exchange(void* rccl, const void* send_lo, void* recv_lo, const void* send_hi, void* recv_hi, size_t bytes)
+    {
+        return ya_comm_exchange((ya_comm*)rccl, send_lo, recv_lo, send_hi, recv_hi, bytes, nullptr);
+    }
+    static int rccl_allreduce(void* rccl, float* buf, int count) { return ya_comm_allreduce_sum((ya_comm*)rccl, buf, count, nullptr); }
     static void* alloc(size_t bytes)
     {
         void* p = nullptr;

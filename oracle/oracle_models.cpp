@@ -24,6 +24,23 @@ void ya_harness_random_sphere(float dist_to_nb, C& cells, unsigned seed)
 // memory is host memory).  Same contracts as include/yalla_hip.h's ya_select_z
 // and ya_gather_rows.
 struct Oracle_slab_ops {
+    // what only the device has (include/slab.cuh: streams, events, RCCL, the split force launch, the fused
+    // update kernels) is refused or absent here
+    static constexpr bool device = false;
+    using Stream = void*;
+    struct Guard_band {
+        float lo_face, hi_face, width;
+    };
+    static constexpr int guard_slots = 0;
+    template<typename Pt>
+    static bool has_generic_forces(const Generic_forces<Pt>&) { return true; }
+    static int rows_over_rccl(void*, void*&, void*&, void*&, const void*, size_t, void*, size_t, const void*, size_t, void*,
+        size_t) { return -7; }
+    static void rows_wait(void*) {}
+    static void rows_path_destroy(void*, void*, void*) {}
+    static int rccl_is(void*, int, int) { return -2; }
+    static int rccl_exchange(void*, const void*, void*, const void*, void*, size_t) { return -7; }
+    static int rccl_allreduce(void*, float*, int) { return -7; }
     static void* alloc(size_t bytes) { return calloc(1, bytes ? bytes : 4); }
     static void zero(void* p, size_t bytes) { memset(p, 0, bytes); }
     static void release(void* p) { free(p); }
