@@ -1010,6 +1010,12 @@ __global__ __launch_bounds__(bits::BLOCK, bits::Min_waves<Pt>::value) void grid_
     YA_BITS_PROBE_END(tile)
 }
 
+}  // namespace ya
+#ifdef YA_EXPERIMENTAL_FORCE_HALVES
+#include "experimental/force_halves.cuh"  // round-5 experiments, both rejected (force_variant 6 / 7: tools/micro/force_ab.hip only)
+#endif
+namespace ya {
+
 // ---------------------------------------------------------------------------------
 // grid_force_coop (the solver's own choice below ~1.5 * 10^5 cells for functors declared YA_STATELESS;
 // forced by Grid_computer::force_variant = 3): the grid force with SEVERAL LANES
@@ -2522,6 +2528,13 @@ public:
         }
     }
     Grid_computer(const Grid_computer&) = delete;
+#ifdef YA_EXPERIMENTAL_FORCE_HALVES
+    float* d_halves_exchange = nullptr;  // (force_variant 6 / 7, tools/micro/force_ab.hip: never freed before exit)
+    int* d_halves_tickets = nullptr;
+    int halves_tiles = 0;
+    long persistent_launches = 0;
+    int persistent_blocks = 0, persistent_tail_turns = 0;
+#endif
     bool sorted_pipeline = true;  // false = both stages through d_X / d_X1 (A/B)
     // z-slab decomposition (include/slab_logic.inc): 1 = the next forces() call launches the tiles
     // in the z-planes next to the slab's faces only (cube ids below force_part_cube_lo or from
@@ -2650,7 +2663,7 @@ protected:
             YA_COOP_LAUNCH(8);
         } else if (lanes == 4) {
             YA_COOP_LAUNCH(4);
-        } else if (force_variant >= 2) {
+        } else if (force_variant >= 2 && force_variant < 6) {
 #define YA_BITS_LAUNCH(stage_v_, gids_)                                                        \
     YA_FORCE_LAUNCH((ya::grid_force_bits<Pt, pw_int, pw_friction, stage_v_, gids_>),           \
         (n + ya::bits::BLOCK - 1) / ya::bits::BLOCK, ya::bits::BLOCK, n, d_cells, d_cells_v,   \
@@ -2671,6 +2684,42 @@ protected:
             }
 #undef YA_BITS_LAUNCH
         }
+#ifdef YA_EXPERIMENTAL_FORCE_HALVES
+        else if (force_variant == 6) {
+            const int tiles = (n + ya::bits::BLOCK - 1) / ya::bits::BLOCK;
+            constexpr int NC = ya::N_floats<Pt>::value + 4;
+            if (halves_tiles < tiles) {
+                if (d_halves_exchange) ya_free(d_halves_exchange), ya_free(d_halves_tickets);
+                halves_tiles = (grid.n_max + ya::bits::BLOCK - 1) / ya::bits::BLOCK;
+                YA_CHECK(ya_malloc((void**)&d_halves_exchange, (size_t)halves_tiles * 2 * NC * ya::bits::BLOCK * sizeof(float)));
+                YA_CHECK(ya_malloc((void**)&d_halves_tickets, (size_t)halves_tiles * sizeof(int)));
+                YA_CHECK(ya_memset_async(d_halves_tickets, 0, (size_t)halves_tiles * sizeof(int), nullptr));
+                YA_CHECK(ya_device_synchronize());
+            }
+            YA_FORCE_LAUNCH((ya::grid_force_halves<Pt, pw_int, pw_friction>), 16 * ((tiles + 7) / 8), ya::bits::BLOCK, n,
+                d_cells, d_cells_v, (const int*)grid.d_cube_id, grid.offsets(), grid.grid_size, grid.n_cubes, cut2, d_dX,
+                has_gen, n_active, d_dX_in_cell_order, d_halves_exchange, d_halves_tickets, tiles);
+        }
+        else if (force_variant == 7) {
+            const int tiles = (n + ya::bits::BLOCK - 1) / ya::bits::BLOCK;
+            constexpr int NC = ya::N_floats<Pt>::value + 4;
+            if (halves_tiles < tiles) {
+                if (d_halves_exchange) ya_free(d_halves_exchange), ya_free(d_halves_tickets);
+                halves_tiles = (grid.n_max + ya::bits::BLOCK - 1) / ya::bits::BLOCK;
+                YA_CHECK(ya_malloc((void**)&d_halves_exchange, (size_t)halves_tiles * 2 * NC * ya::bits::BLOCK * sizeof(float)));
+                YA_CHECK(ya_malloc((void**)&d_halves_tickets, ((size_t)halves_tiles + 512) * sizeof(int)));
+                YA_CHECK(ya_memset_async(d_halves_tickets, 0, ((size_t)halves_tiles + 512) * sizeof(int), nullptr));
+                YA_CHECK(ya_device_synchronize());
+            }
+            int* queues = d_halves_tickets + halves_tiles;  // two sets of 8 (a cache line each), used alternately
+            const int set = (int)(persistent_launches++ & 1);
+            const int resident = persistent_blocks > 0 ? persistent_blocks : 5120;
+            YA_FORCE_LAUNCH((ya::grid_force_persistent<Pt, pw_int, pw_friction>), resident < tiles ? resident : tiles,
+                ya::bits::BLOCK, n, d_cells, d_cells_v, (const int*)grid.d_cube_id, grid.offsets(), grid.grid_size, grid.n_cubes,
+                cut2, d_dX, has_gen, n_active, d_dX_in_cell_order, d_halves_exchange, d_halves_tickets, queues + 256 * set,
+                queues + 256 * (1 - set), tiles, persistent_tail_turns);
+        }
+#endif
 #ifdef YA_EXPERIMENTAL_FORCE_VARIANTS
         else if (force_variant == 0) {
             YA_FORCE_LAUNCH((ya::grid_force_direct<Pt, pw_int, pw_friction>), blocks, ya::FORCE_BLOCK, n,

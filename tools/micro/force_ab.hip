@@ -42,6 +42,12 @@ struct Probe : public Solution<Pt, Grid_solver> {
         this->coop_lanes = YA_COOP_LANES;  // variant 3: fixed instead of chosen from n
 #endif
         this->stage_v_max = variant >= 10 ? 2000000000 : 0;
+#if defined(AB_TAIL_TURNS) && defined(YA_EXPERIMENTAL_FORCE_HALVES)
+        this->persistent_tail_turns = AB_TAIL_TURNS;  // variant 7: an XCD's last this-many tiles as halves
+#endif
+#if defined(AB_PERSISTENT_BLOCKS) && defined(YA_EXPERIMENTAL_FORCE_HALVES)
+        this->persistent_blocks = AB_PERSISTENT_BLOCKS;
+#endif
         this->template forces<models::spring, friction_w_neighbour<Pt>>(
             n, this->d_sorted, this->d_sorted_v, out, false, n, out_sorted);
     }

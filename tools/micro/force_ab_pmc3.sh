@@ -12,7 +12,7 @@ for exe in $GRAFT_REPO_ROOT/tools/micro/ab_bin/force_ab_*; do
     i=$((i+1))
     rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $out/$tag.$i -o p -- $exe "$@" > /dev/null 2>$out/$tag.$i.err
   done
-  python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py "$out/$tag.*/*counter_collection.csv" grid_force_bits > $out/$tag.txt
+  python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py "$out/$tag.*/*counter_collection.csv" grid_force > $out/$tag.txt
   rm -rf $out/$tag.1 $out/$tag.2
   echo "== $tag"; cat $out/$tag.txt
 done
