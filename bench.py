@@ -209,7 +209,7 @@ def kernel_source_sha():
 
 
 def counters_key(args, n_total):
-    """Key of this workload in profiles/r04_counters.json (None: no counters kept for it)."""
+    """Key of this workload in profiles/r05_counters.json (None: no counters kept for it)."""
     if args.slab or args.gpus > 1 or args.force_variant not in (-1, 2):
         return None
     tier = "" if args.arith == "exact" else "_fast"
@@ -229,11 +229,11 @@ def counters_key(args, n_total):
 
 def measured_counters(kernel_key):
     """Per-launch PMC figures of the dominant kernel from the committed rocprofv3 passes of
-    this same command (profiles/r04_counters.json, written by tools/roofline_json.py):
+    this same command (profiles/r05_counters.json, written by tools/roofline_json.py):
     HBM-side traffic (FETCH_SIZE and WRITE_SIZE from separate --pmc passes, KiB, FETCH_SIZE
     doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950) and the
     ceilings that bind this kernel.  Returns ({}, None) when there is no record."""
-    path = os.path.join(ROOT, "profiles", "r04_counters.json")
+    path = os.path.join(ROOT, "profiles", "r05_counters.json")
     try:
         with open(path) as f:
             rec = json.load(f)[kernel_key]
@@ -246,7 +246,7 @@ def measured_counters(kernel_key):
     head = {"commit": rec.get("head"), "kernel_sha": rec.get("kernel_sha")}
     if rec.get("kernel_sha") != kernel_source_sha():
         # measured on an older kernel: do not pass the numbers off as this build's
-        sys.stderr.write("bench.py: profiles/r04_counters.json[%s] was measured on another kernel source "
+        sys.stderr.write("bench.py: profiles/r05_counters.json[%s] was measured on another kernel source "
                          "(%s != %s); traffic and PMC fractions omitted\n" % (kernel_key, rec.get("kernel_sha"), kernel_source_sha()))
         return {"stale_counters": True}, head
     return out, head
