@@ -34,6 +34,7 @@ def hip():
     lib.ya_gather_rows_pair.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, i32, vp]
     lib.ya_reduce_sum_packed.argtypes = [vp, i32, i32, vp, vp, vp]
     lib.ya_reduce_mean.argtypes = [vp, i32, i32, vp, vp, vp]
+    lib.ya_reduce_partials.argtypes = [vp, i32, i32, vp, C.POINTER(C.c_int), vp]
     lib.ya_reduce_workspace_bytes.restype = sz
     lib.ya_reduce_workspace_bytes.argtypes = [i32]
     lib.ya_device_synchronize.argtypes = []
@@ -293,6 +294,46 @@ def test_reduce_mean_matches_its_documented_order(hip, n, nf):
     assert np.array_equal(out[nf:].view(np.uint32), total.view(np.uint32))
     inv = np.float32(1.0 / np.float64(np.float32(n)))
     assert np.array_equal(out[:nf].view(np.uint32), (total * inv).view(np.uint32))
+
+
+@pytest.mark.parametrize("n,nf", [(1, 3), (70000, 5), (1234567, 3)])
+def test_reduce_partials_are_the_first_half_of_reduce_mean(hip, n, nf):
+    """ya_reduce_partials (round 5: the update kernels fold these themselves): B = clamp(ceil(n / 256), 1, 1024)
+    per-block sums in the documented order; folded as ya::fixed_velocity_from_partials folds them they give the
+    bits ya_reduce_mean leaves."""
+    rng = np.random.default_rng(5)
+    v = (rng.random((n, nf), dtype=np.float32) - 0.5).astype(np.float32)
+    dv = Dev(hip, v)
+    d_ws = Dev(hip, nbytes=hip.ya_reduce_workspace_bytes(nf))
+    count = C.c_int(0)
+    assert hip.ya_reduce_partials(dv.p, nf, n, d_ws.p, C.byref(count), None) == 0
+    B = min(max((n + 255) // 256, 1), 1024)
+    assert count.value == B
+    assert hip.ya_device_synchronize() == 0
+    part = d_ws.get(np.float32, B * nf).reshape(B, nf)
+
+    def fold(a):  # a: (..., 256, nf)
+        s = 128
+        while s >= 1:
+            a = a[..., :s, :] + a[..., s:2 * s, :]
+            s //= 2
+        return a[..., 0, :]
+    pad = np.zeros((B * 256 * ((n + B * 256 - 1) // (B * 256)), nf), np.float32)
+    pad[:n] = v
+    acc = np.zeros((B, 256, nf), np.float32)
+    for chunk in pad.reshape(-1, B, 256, nf):
+        acc = acc + chunk
+    assert np.array_equal(part.view(np.uint32), fold(acc).view(np.uint32))
+    # ... and the second half, as the update kernels do it
+    lanes = np.zeros((256 * ((B + 255) // 256), nf), np.float32)
+    lanes[:B] = part
+    acc2 = np.zeros((256, nf), np.float32)
+    for chunk in lanes.reshape(-1, 256, nf):
+        acc2 = acc2 + chunk
+    d_out = Dev(hip, nbytes=8 * nf)
+    assert hip.ya_reduce_mean(dv.p, nf, n, d_out.p, d_ws.p, None) == 0
+    out = d_out.get(np.float32, 2 * nf)
+    assert np.array_equal(out[nf:].view(np.uint32), fold(acc2).view(np.uint32))
 
 
 # ---- round 4 entry points ---------------------------------------------------------------------------

@@ -135,19 +135,23 @@ def test_both_second_stage_pipelines_agree(oracle, device):
     """The second Heun stage built from the cube-sorted cells (default) and from d_X1
     (the reference's structure) are the same arithmetic: bit-identical positions,
     velocities and grid arrays, for a 16-byte and a 24-byte point entry."""
-    for model, n, dt in (("springs_grid", 60000, 0.001), ("relu_po_grid", 20000, 0.1)):
+    for model, n, dt in (("springs_grid", 60000, 0.001), ("relu_po_grid", 20000, 0.1), ("springs_grid", 300000, 0.001)):
         res = []
-        for sorted_pipeline in (0, 1):
+        # (2 = the sorted pipeline with ya_reduce_mean's own second launch instead of the update kernels
+        # folding the partial sums themselves, round 5: the same tree, the same bits)
+        for sorted_pipeline in (0, 1, 2):
             with Solution(model, n, 64, 1.0, lib=device) as s:
                 s.random_sphere(0.5, 11)
+                s.set_param("force_variant", 2)   # (one kernel for every size: the comparison is about the pipelines)
                 s.set_param("sorted_pipeline", sorted_pipeline)
                 s.take_step(dt, 3)
                 res.append((s.positions(), s.old_v(), s.grid()))
-        (Xa, va, ga), (Xb, vb, gb) = res
-        assert np.array_equal(Xa.view(np.uint32), Xb.view(np.uint32)), model
-        assert np.array_equal(va.view(np.uint32), vb.view(np.uint32)), model
-        for a, b in zip(ga, gb):
-            assert np.array_equal(a, b), model
+        Xa, va, ga = res[0]
+        for Xb, vb, gb in res[1:]:
+            assert np.array_equal(Xa.view(np.uint32), Xb.view(np.uint32)), model
+            assert np.array_equal(va.view(np.uint32), vb.view(np.uint32)), model
+            for a, b in zip(ga, gb):
+                assert np.array_equal(a, b), model
 
 
 def test_randomised_configurations_bit_exact(oracle, device):
