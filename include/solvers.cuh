@@ -1650,6 +1650,52 @@ __global__ __launch_bounds__(ya::UPDATE_BLOCK) void euler_step_sorted_folding(co
     d_sorted[s] = e;
 }
 
+// euler_step / heun_step (the pipeline through d_X / d_X1: generic forces, Tile_solver, Gabriel_solver) with the
+// fixed velocity folded here; euler_step_folding leaves it in d_fix_out.
+template<typename Pt>
+__global__ __launch_bounds__(ya::UPDATE_BLOCK) void euler_step_folding(const int n, const float dt,
+    const Pt* __restrict__ d_X0, const float* __restrict__ partials, const int n_partials, float* __restrict__ d_fix_out,
+    Pt* __restrict__ d_dX, Pt* __restrict__ d_X)
+{
+    const float3 fix = ya::fixed_velocity_from_partials<ya::N_floats<Pt>::value>(partials, n_partials, n);
+    const int i = blockIdx.x * ya::UPDATE_BLOCK + threadIdx.x;
+    if (i == 0) {
+        d_fix_out[0] = fix.x;
+        d_fix_out[1] = fix.y;
+        d_fix_out[2] = fix.z;
+    }
+    if (i >= n) return;
+
+    Pt dX = d_dX[i];
+    dX.x -= fix.x;
+    dX.y -= fix.y;
+    dX.z -= fix.z;
+    d_dX[i] = dX;
+    d_X[i] = d_X0[i] + dX * dt;
+}
+
+template<typename Pt>
+__global__ __launch_bounds__(ya::UPDATE_BLOCK) void heun_step_folding(const int n, const float dt,
+    const Pt* __restrict__ d_dX, const float* __restrict__ partials1, const int n_partials1, Pt* __restrict__ d_dX1,
+    Pt* __restrict__ d_X, float3* __restrict__ d_old_v)
+{
+    const float3 fix1 = ya::fixed_velocity_from_partials<ya::N_floats<Pt>::value>(partials1, n_partials1, n);
+    const int i = blockIdx.x * ya::UPDATE_BLOCK + threadIdx.x;
+    if (i >= n) return;
+
+    Pt dX1 = d_dX1[i];
+    dX1.x -= fix1.x;
+    dX1.y -= fix1.y;
+    dX1.z -= fix1.z;
+    d_dX1[i] = dX1;
+    const Pt dX = d_dX[i];
+    Pt X = d_X[i];
+    X += (dX + dX1) * 0.5 * dt;
+    d_X[i] = X;
+    d_old_v[i] = float3{
+        (dX.x + dX1.x) * 0.5f, (dX.y + dX1.y) * 0.5f, (dX.z + dX1.z) * 0.5f};
+}
+
 // heun_step_raw with the second stage's fixed velocity folded from its partial sums.
 template<typename Pt>
 __global__ __launch_bounds__(ya::UPDATE_BLOCK) void heun_step_raw_folding(const int n, const float dt,
@@ -2157,6 +2203,26 @@ protected:
                 n, dt, d_dX, d_fix_velocity, d_dX1, d_X, d_old_v);
     }
 
+    // stage_update for set_fixed() (the default) with the fixed velocity folded by the update kernels themselves
+    // from the stage's partial sums (two launches fewer per step, the same bits: see
+    // ya::fixed_velocity_from_partials).  The sorted copy's predictor runs first and leaves the velocity for
+    // euler_step; without a sorted copy (Tile_solver, Gabriel_solver) euler_step_folding does both.
+    void stage_update_folding(int stage, int n, float dt)
+    {
+        const int blocks = (n + ya::UPDATE_BLOCK - 1) / ya::UPDATE_BLOCK;
+        int n_partials = 0;
+        YA_CHECK(ya_reduce_partials(stage == 1 ? d_dX : d_dX1, n_floats, n, d_workspace, &n_partials, nullptr));
+        if (stage == 1 && sorted_stage_cells == n) {
+            Computer<Pt>::predictor_in_sorted_space_folding(n, dt, d_workspace, n_partials, d_mean_first);
+            euler_step<<<blocks, ya::UPDATE_BLOCK>>>(n, dt, d_X, d_mean_first, d_dX, d_X1);
+        } else if (stage == 1) {
+            sorted_stage_cells = -1;
+            euler_step_folding<<<blocks, ya::UPDATE_BLOCK>>>(n, dt, d_X, d_workspace, n_partials, d_mean_first, d_dX, d_X1);
+        } else {
+            heun_step_folding<<<blocks, ya::UPDATE_BLOCK>>>(n, dt, d_dX, d_workspace, n_partials, d_dX1, d_X, d_old_v);
+        }
+    }
+
     // The two updates of a z-slab's step without generic forces: stage 1 entirely inside the
     // sorted copy (own and mirrored cells, one launch; d_dX stays raw, d_X1 is not written), stage 2
     // with both fixed velocities subtracted in the corrector.  Returns false if stage 1 left no
@@ -2310,13 +2376,20 @@ protected:
         }
         last_key = Step_key{};
 
+        const bool folding = fix_com and !fix_com_z and fold_in_update;
         // 1st stage
         stage_rhs<pw_int, pw_friction>(1, n, n, gen_forces);
-        stage_update(1, n, dt, fix_velocity(n, d_dX, fix_com or fix_com_z, fix_com_z));
+        if (folding)
+            stage_update_folding(1, n, dt);
+        else
+            stage_update(1, n, dt, fix_velocity(n, d_dX, fix_com or fix_com_z, fix_com_z));
 
         // 2nd stage
         stage_rhs<pw_int, pw_friction>(2, n, n, gen_forces);
-        stage_update(2, n, dt, fix_velocity(n, d_dX1, fix_com, false));
+        if (folding)
+            stage_update_folding(2, n, dt);
+        else
+            stage_update(2, n, dt, fix_velocity(n, d_dX1, fix_com, false));
     }
 };
 
