@@ -154,7 +154,9 @@ constexpr int UPDATE_BLOCK = 256;
 // One cell in cube-sorted order: the point and its original id.  16-byte
 // entries (float3) load as one dwordx4.
 template<typename Pt>
-struct alignas((sizeof(Pt) + 4) % 16 == 0 ? 16 : ((sizeof(Pt) + 4) % 8 == 0 ? 8 : 4)) Entry {
+struct alignas(alignof(Pt) > ((sizeof(Pt) + 4) % 16 == 0 ? 16 : ((sizeof(Pt) + 4) % 8 == 0 ? 8 : 4))
+                   ? alignof(Pt)
+                   : ((sizeof(Pt) + 4) % 16 == 0 ? 16 : ((sizeof(Pt) + 4) % 8 == 0 ? 8 : 4))) Entry {
     Pt X;
     int id;
 };
@@ -1652,10 +1654,14 @@ __global__ __launch_bounds__(ya::UPDATE_BLOCK) void euler_step_sorted_folding(co
 
 // euler_step / heun_step (the pipeline through d_X / d_X1: generic forces, Tile_solver, Gabriel_solver) with the
 // fixed velocity folded here; euler_step_folding leaves it in d_fix_out.
+// (d_sorted, may be NULL: the cube-sorted copy's predictor in the same launch, euler_step_sorted's statements for
+// slot i; d_zero, may be NULL: the NEXT stage's right-hand side array, whose row i is dead by now and is left
+// zeroed for the generic forces that will add to it -- a memset launch less)
 template<typename Pt>
 __global__ __launch_bounds__(ya::UPDATE_BLOCK) void euler_step_folding(const int n, const float dt,
     const Pt* __restrict__ d_X0, const float* __restrict__ partials, const int n_partials, float* __restrict__ d_fix_out,
-    Pt* __restrict__ d_dX, Pt* __restrict__ d_X)
+    Pt* __restrict__ d_dX, Pt* __restrict__ d_X, const Pt* __restrict__ d_dX_sorted, ya::Entry<Pt>* __restrict__ d_sorted,
+    Pt* __restrict__ d_zero)
 {
     const float3 fix = ya::fixed_velocity_from_partials<ya::N_floats<Pt>::value>(partials, n_partials, n);
     const int i = blockIdx.x * ya::UPDATE_BLOCK + threadIdx.x;
@@ -1666,18 +1672,29 @@ __global__ __launch_bounds__(ya::UPDATE_BLOCK) void euler_step_folding(const int
     }
     if (i >= n) return;
 
+    if (d_sorted) {
+        Pt dXs = d_dX_sorted[i];
+        dXs.x -= fix.x;
+        dXs.y -= fix.y;
+        dXs.z -= fix.z;
+        ya::Entry<Pt> e = d_sorted[i];
+        e.X = e.X + dXs * dt;
+        d_sorted[i] = e;
+    }
     Pt dX = d_dX[i];
     dX.x -= fix.x;
     dX.y -= fix.y;
     dX.z -= fix.z;
     d_dX[i] = dX;
     d_X[i] = d_X0[i] + dX * dt;
+    if (d_zero) d_zero[i] = ya::zero<Pt>();
 }
 
+// (zero_dX: row i of d_dX, dead after this, is left zeroed for the next step's generic forces)
 template<typename Pt>
 __global__ __launch_bounds__(ya::UPDATE_BLOCK) void heun_step_folding(const int n, const float dt,
-    const Pt* __restrict__ d_dX, const float* __restrict__ partials1, const int n_partials1, Pt* __restrict__ d_dX1,
-    Pt* __restrict__ d_X, float3* __restrict__ d_old_v)
+    Pt* __restrict__ d_dX, const float* __restrict__ partials1, const int n_partials1, Pt* __restrict__ d_dX1,
+    Pt* __restrict__ d_X, float3* __restrict__ d_old_v, const bool zero_dX)
 {
     const float3 fix1 = ya::fixed_velocity_from_partials<ya::N_floats<Pt>::value>(partials1, n_partials1, n);
     const int i = blockIdx.x * ya::UPDATE_BLOCK + threadIdx.x;
@@ -1694,6 +1711,7 @@ __global__ __launch_bounds__(ya::UPDATE_BLOCK) void heun_step_folding(const int 
     d_X[i] = X;
     d_old_v[i] = float3{
         (dX.x + dX1.x) * 0.5f, (dX.y + dX1.y) * 0.5f, (dX.z + dX1.z) * 0.5f};
+    if (zero_dX) d_dX[i] = ya::zero<Pt>();
 }
 
 // heun_step_raw with the second stage's fixed velocity folded from its partial sums.
@@ -2076,6 +2094,7 @@ protected:
     ya_n_reader* n_reader = nullptr;
     int sorted_stage_cells = -1;  // stage API: cells in the sorted copy stage 2 may start from
     bool mirrored_in_sorted_copy = false;  // ... and the mirrored cells' predictor is in it already
+    int rhs_zeroed[2] = {0, 0};        // rows of d_dX / d_dX1 an update kernel left zeroed (stage_update_folding)
     std::function<void()> keep_order;  // keep_in_cube_order: renumber(the registered arrays)
     int keep_order_every = 0, keep_order_wait = 0;
     bool fix_com = true;
@@ -2158,9 +2177,11 @@ protected:
         Pt* d_rhs = stage == 1 ? d_dX : d_dX1;
         const bool has_gen = !ya::is_no_gen_forces<Pt>(gen_forces);
         if (has_gen) {
-            YA_CHECK(ya_memset_async(d_rhs, 0, (size_t)n * sizeof(Pt), nullptr));
+            // (the update kernel before this stage may have left the rows zeroed already: stage_update_folding)
+            if (rhs_zeroed[stage - 1] < n) YA_CHECK(ya_memset_async(d_rhs, 0, (size_t)n * sizeof(Pt), nullptr));
             gen_forces(n, d_in, d_rhs);
         }
+        rhs_zeroed[stage - 1] = 0;  // the force kernel writes it next
         if (stage == 2 && sorted_stage_cells == n) {
             // sorted-space second stage (see take_step): the own cells were moved by
             // stage_update(1), the ghost cells' new positions are in d_X1 (which the
@@ -2207,19 +2228,24 @@ protected:
     // from the stage's partial sums (two launches fewer per step, the same bits: see
     // ya::fixed_velocity_from_partials).  The sorted copy's predictor runs first and leaves the velocity for
     // euler_step; without a sorted copy (Tile_solver, Gabriel_solver) euler_step_folding does both.
-    void stage_update_folding(int stage, int n, float dt)
+    // With generic forces (`zeroing`) the same kernels leave the right-hand side array of the NEXT stage zeroed --
+    // d_dX1 after the predictor, d_dX after the corrector: both dead by then -- so that the memset in front of the
+    // generic forces (solvers.cuh:232,258 `thrust::fill`) need not be launched (rhs_zeroed: rows known to be zero).
+    void stage_update_folding(int stage, int n, float dt, bool zeroing)
     {
         const int blocks = (n + ya::UPDATE_BLOCK - 1) / ya::UPDATE_BLOCK;
         int n_partials = 0;
         YA_CHECK(ya_reduce_partials(stage == 1 ? d_dX : d_dX1, n_floats, n, d_workspace, &n_partials, nullptr));
-        if (stage == 1 && sorted_stage_cells == n) {
-            Computer<Pt>::predictor_in_sorted_space_folding(n, dt, d_workspace, n_partials, d_mean_first);
-            euler_step<<<blocks, ya::UPDATE_BLOCK>>>(n, dt, d_X, d_mean_first, d_dX, d_X1);
-        } else if (stage == 1) {
-            sorted_stage_cells = -1;
-            euler_step_folding<<<blocks, ya::UPDATE_BLOCK>>>(n, dt, d_X, d_workspace, n_partials, d_mean_first, d_dX, d_X1);
+        if (stage == 1) {
+            const bool with_sorted = sorted_stage_cells == n;
+            if (!with_sorted) sorted_stage_cells = -1;
+            euler_step_folding<<<blocks, ya::UPDATE_BLOCK>>>(n, dt, d_X, d_workspace, n_partials, d_mean_first, d_dX, d_X1,
+                with_sorted ? Computer<Pt>::sorted_rhs() : nullptr, with_sorted ? Computer<Pt>::sorted_cells() : nullptr,
+                zeroing ? d_dX1 : nullptr);
+            rhs_zeroed[1] = zeroing ? n : 0;
         } else {
-            heun_step_folding<<<blocks, ya::UPDATE_BLOCK>>>(n, dt, d_dX, d_workspace, n_partials, d_dX1, d_X, d_old_v);
+            heun_step_folding<<<blocks, ya::UPDATE_BLOCK>>>(n, dt, d_dX, d_workspace, n_partials, d_dX1, d_X, d_old_v, zeroing);
+            rhs_zeroed[0] = zeroing ? n : 0;
         }
     }
 
@@ -2274,6 +2300,7 @@ protected:
     void sorted_step(const int n, const float dt)
     {
         const int blocks = (n + ya::UPDATE_BLOCK - 1) / ya::UPDATE_BLOCK;
+        rhs_zeroed[0] = rhs_zeroed[1] = 0;  // both right-hand side arrays are written here
         Computer<Pt>::template pwints<pw_int, pw_friction>(n, d_X, d_old_v, d_dX, false, n, true);
         if (fix_com and !fix_com_z and fold_in_update) {
             // set_fixed() (the default): both fixed velocities are means, folded by the update kernels
@@ -2379,15 +2406,16 @@ protected:
         const bool folding = fix_com and !fix_com_z and fold_in_update;
         // 1st stage
         stage_rhs<pw_int, pw_friction>(1, n, n, gen_forces);
+        const bool zeroing = !ya::is_no_gen_forces<Pt>(gen_forces);
         if (folding)
-            stage_update_folding(1, n, dt);
+            stage_update_folding(1, n, dt, zeroing);
         else
             stage_update(1, n, dt, fix_velocity(n, d_dX, fix_com or fix_com_z, fix_com_z));
 
         // 2nd stage
         stage_rhs<pw_int, pw_friction>(2, n, n, gen_forces);
         if (folding)
-            stage_update_folding(2, n, dt);
+            stage_update_folding(2, n, dt, zeroing);
         else
             stage_update(2, n, dt, fix_velocity(n, d_dX1, fix_com, false));
     }
@@ -2422,6 +2450,8 @@ protected:
     void ids_changed() {}
     void predictor_in_sorted_space(int, float, const float*, int) {}
     void predictor_in_sorted_space_folding(int, float, const float*, int, float*) {}
+    const Pt* sorted_rhs() const { return nullptr; }
+    ya::Entry<Pt>* sorted_cells() { return nullptr; }
     void predictor_in_sorted_space_mirrored(int, float, const float*, float*, int, const Pt*, int, float*, ya::Guard_band) {}
     void ghosts_in_sorted_space(int, int, const Pt*) {}
     template<Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction>
@@ -2850,6 +2880,8 @@ protected:
         euler_step_sorted<<<(n + ya::UPDATE_BLOCK - 1) / ya::UPDATE_BLOCK, ya::UPDATE_BLOCK, 0, stream>>>(
             n, dt, d_fix, d_dX_sorted, d_sorted, n_active);
     }
+    const Pt* sorted_rhs() const { return d_dX_sorted; }
+    ya::Entry<Pt>* sorted_cells() { return d_sorted; }
     void predictor_in_sorted_space_folding(const int n, const float dt, const float* d_partials, const int n_partials,
         float* d_fix_out)
     {

@@ -90,6 +90,14 @@ def test_arrays_registered_once_are_kept_in_cube_order():
 
 
 @pytest.mark.gpu
+def test_folding_updates_match_the_plain_pipeline():
+    """Round 5's update kernels (the centre-of-mass fold inside them, the next stage's right-hand side zeroed for
+    the generic forces): steps with and without generic forces in turn, cells appended between steps, Grid and
+    Tile solvers -- bit for bit the plain pipeline's states."""
+    run("test_folding", "ALL FOLDING TESTS PASSED")
+
+
+@pytest.mark.gpu
 def test_force_launch_trace(tmp_path):
     """tools/micro/force_trace.hip (the force kernel built with -DYA_BITS_TRACE: every workgroup
     stamps its start, end, CU and XCD) through tools/force_trace_summary.py: one workgroup per
