@@ -145,10 +145,13 @@ __device__ __forceinline__ int block_sum(int v, int* sh)
 // first -- one 64-bit word {1, total}, stored and read past the XCDs' L2s (device-scope atomics) -- and
 // then collects the totals of the tiles before it, waiting for those not yet there.  A block only ever
 // waits for blocks with LOWER indices, which the dispatcher started before it and which publish before
-// they wait themselves: no cycle.  The block that is through last (a ticket) clears the words again.
+// they wait themselves: no cycle.  A word is valid if its upper half is the scan's EPOCH, a counter in device
+// memory that the launch's last block moves on when it is through (by then every block has published, hence
+// read the epoch): nothing is cleared, no ticket is drawn (1000 blocks drawing tickets from one address were
+// 8 us of a 10 M-cell build's scan), and a captured graph replays correctly.
 // (first_tile: the scan of a cube range, ya_grid_set_cube_range -- block b works on tile first_tile + b)
 __global__ __launch_bounds__(BLOCK) void k_scan(int* __restrict__ count,
-    unsigned long long* __restrict__ tile_state, int* __restrict__ ticket, int n_cubes, int n,
+    unsigned long long* __restrict__ tile_state, unsigned* __restrict__ d_epoch, int n_cubes, int n,
     int* __restrict__ offs, int* __restrict__ cube_start, int* __restrict__ cube_end,
     const int* __restrict__ d_n, int first_tile, int all_tiles)
 {
@@ -156,6 +159,7 @@ __global__ __launch_bounds__(BLOCK) void k_scan(int* __restrict__ count,
     __shared__ int sh[4];
     __shared__ int sh_wave[4];
     const int tile = first_tile + blockIdx.x;
+    const unsigned long long epoch = *d_epoch;  // (the last scan's last block left it; a kernel boundary lies between)
 
     size_t base = (size_t)tile * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
     int4* c4 = reinterpret_cast<int4*>(count + base);
@@ -175,15 +179,27 @@ __global__ __launch_bounds__(BLOCK) void k_scan(int* __restrict__ count,
     __syncthreads();
     if (threadIdx.x == 0)
         __hip_atomic_store(&tile_state[tile],
-            (1ULL << 32) | (unsigned)(sh_wave[0] + sh_wave[1] + sh_wave[2] + sh_wave[3]), __ATOMIC_RELAXED,
+            (epoch << 32) | (unsigned)(sh_wave[0] + sh_wave[1] + sh_wave[2] + sh_wave[3]), __ATOMIC_RELAXED,
             __HIP_MEMORY_SCOPE_AGENT);
     // cells in all tiles before this one (a cube range: no cell lies below its first tile)
+    // (eight words per thread asked for at once: the loads go past the L2s, ~2 us each, and a block of a
+    // 1000-tile grid needs four or five of them per thread -- one after the other they were 10 us of the launch)
     int before = 0;
-    for (int t = first_tile + threadIdx.x; t < tile; t += BLOCK) {
-        unsigned long long v;
-        while (!((v = __hip_atomic_load(&tile_state[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32))
-            __builtin_amdgcn_s_sleep(1);
-        before += (int)(unsigned)v;
+    for (int t0 = first_tile + threadIdx.x; t0 < tile; t0 += 8 * BLOCK) {
+        unsigned long long v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            v[k] = t0 + k * BLOCK < tile
+                       ? __hip_atomic_load(&tile_state[t0 + k * BLOCK], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                       : epoch << 32;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            while ((v[k] >> 32) != epoch) {  // not published yet
+                __builtin_amdgcn_s_sleep(1);
+                v[k] = __hip_atomic_load(&tile_state[t0 + k * BLOCK], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            before += (int)(unsigned)v[k];
+        }
     }
     before = block_sum(before, sh);
     int wave_off = 0;
@@ -211,15 +227,10 @@ __global__ __launch_bounds__(BLOCK) void k_scan(int* __restrict__ count,
     c4[1] = make_int4(0, 0, 0, 0);
     if (tile == all_tiles - 1 && threadIdx.x == BLOCK - 1)
         offs[(size_t)all_tiles * SCAN_TILE] = n;
-    // the block that is through last leaves the published totals cleared for the next scan (block_sum's
-    // barriers lie between every thread's reads of them and this ticket)
-    __shared__ int sh_last;
-    if (threadIdx.x == 0) sh_last = atomicAdd(ticket, 1) == (int)gridDim.x - 1;
-    __syncthreads();
-    if (sh_last) {
-        for (int t = first_tile + threadIdx.x; t < first_tile + (int)gridDim.x; t += BLOCK)
-            __hip_atomic_store(&tile_state[t], 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (threadIdx.x == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // the launch's last block has seen every other block's word: all of them have read the epoch
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        const unsigned next = (unsigned)epoch + 1u;
+        __hip_atomic_store(d_epoch, next ? next : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -804,8 +815,8 @@ struct ya_grid {
     size_t padded;  // n_cubes rounded up to whole scan tiles
     int *d_cube_id, *d_point_id, *d_cube_start, *d_cube_end;  // public
     int *d_offs, *d_count;                                    // private
-    unsigned long long* d_tile_state;  // k_scan: a tile's published total, [n_tiles]; zero between scans
-    int* d_scan_ticket;
+    unsigned long long* d_tile_state;  // k_scan: a tile's published total {epoch, total}, [n_tiles]
+    unsigned* d_scan_epoch;            // ... valid if its upper half is this
     int *d_cube_of, *d_rank, *d_arrival;                      // private, [n_max]
     int *d_arrival_src;  // visit position of the cell that arrived in a slot
     float* d_stash;      // the points in visit order (ya_grid_build_sorted), lazily sized
@@ -922,9 +933,12 @@ static int grid_allocate(ya_grid* g, int n_max)
     YA_TRY(hipMalloc(&g->d_offs, cb));
     YA_TRY(hipMalloc(&g->d_count, cb));
     YA_TRY(hipMalloc(&g->d_tile_state, (size_t)g->n_tiles * sizeof(unsigned long long)));
-    YA_TRY(hipMalloc(&g->d_scan_ticket, sizeof(int)));
+    YA_TRY(hipMalloc(&g->d_scan_epoch, sizeof(unsigned)));
     YA_TRY(hipMemset(g->d_tile_state, 0, (size_t)g->n_tiles * sizeof(unsigned long long)));
-    YA_TRY(hipMemset(g->d_scan_ticket, 0, sizeof(int)));
+    {
+        const unsigned one = 1;  // (the zeroed words are invalid)
+        YA_TRY(hipMemcpy(g->d_scan_epoch, &one, sizeof(one), hipMemcpyHostToDevice));
+    }
     YA_TRY(hipMalloc(&g->d_status, sizeof(int)));
     YA_TRY(hipMemset(g->d_count, 0, cb));
     YA_TRY(hipMemset(g->d_offs, 0, cb));
@@ -985,7 +999,7 @@ int ya_grid_destroy(ya_grid* g)
     (void)hipFree(g->d_offs);
     (void)hipFree(g->d_count);
     (void)hipFree(g->d_tile_state);
-    (void)hipFree(g->d_scan_ticket);
+    (void)hipFree(g->d_scan_epoch);
     (void)hipFree(g->d_status);
     free(g);
     return 0;
@@ -1015,7 +1029,7 @@ static void launch_scan(ya_grid* g, int n, const int* d_n, hipStream_t st)
     const bool range_only = g->range_n >= 0 && g->range_n == n && !d_n;
     const int first = range_only ? g->range_first_tile : 0;
     const int tiles = range_only ? g->range_end_tile - g->range_first_tile : g->n_tiles;
-    k_scan<<<tiles, BLOCK, 0, st>>>(g->d_count, g->d_tile_state, g->d_scan_ticket, g->n_cubes, n, g->d_offs, g->d_cube_start,
+    k_scan<<<tiles, BLOCK, 0, st>>>(g->d_count, g->d_tile_state, g->d_scan_epoch, g->n_cubes, n, g->d_offs, g->d_cube_start,
         g->d_cube_end, d_n, first, g->n_tiles);
     if (!range_only && g->range_first_tile >= 0) g->range_n = d_n ? -1 : n;
 }
