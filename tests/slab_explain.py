@@ -21,6 +21,12 @@ from yalla_amd import slab as slab_mod
 from yalla_amd.solution import Solution
 
 
+# The order of the centre-of-mass sums: 1 = the device's tree (B blocks x 256 lanes, folded by halving; the
+# oracle's YA_REDUCE_TREE) -- with it the oracle's runs, undivided and in slabs, are the device's bit for bit,
+# so what is explained here is what the device did; 0 = the reference-like serial sum.
+REDUCE_ORDER = 1
+
+
 def _trace(lib, ids, margin, run):
     """run() with the pair trace armed for `ids`; returns {(call, i): {j: dist}}."""
     lib.ya_oracle_trace_begin.argtypes = [C.POINTER(C.c_int), C.c_int, C.c_float]
@@ -44,7 +50,7 @@ def _trace(lib, ids, margin, run):
 def undivided_snapshots(lib, n, gs, dist, seed, dt, steps, model):
     """X0 and the positions after every step of the undivided system."""
     with Solution(model, n, gs, 1.0, lib=lib) as s:
-        s.set_reduce_order(0)
+        s.set_reduce_order(REDUCE_ORDER)
         s.random_sphere(dist, seed)
         if model.startswith("sorting"):
             s.set_param("n_cells", n)
@@ -61,8 +67,9 @@ def slab_snapshots(lib, X0, world, gs, dt, steps, migrate_every, model):
     yalla_amd.slab.run_slabs' schedule: migration every `migrate_every`-th step and after the last one)."""
     plan = slab_mod.slab_plan(X0, world, 1.0, lib)
     slabs = [slab_mod.Slab(model, X0, r, world, gs, lib=lib, plan=plan) for r in range(world)]
-    if model.startswith("sorting"):
-        for s in slabs:
+    for s in slabs:
+        s.sim.set_reduce_order(REDUCE_ORDER)
+        if model.startswith("sorting"):
             s.sim.set_param("n_cells", len(X0))
     shared = slab_mod.ThreadTransport.Shared(world, False)
     for r, s in enumerate(slabs):
