@@ -489,6 +489,36 @@ def test_rccl_communicator_single_rank(device):
 
 
 @pytest.mark.gpu
+def test_communicator_facts_gathered_over_several_ranks(device):
+    """NativeComm.gather_info with more than one rank (what bench.py prints as "rccl" and checks against --gpus): four
+    loopback communicators, a host thread each -- every rank ends up with the same list, one entry per rank in
+    rank order.  (RCCL itself refuses two ranks on one GPU; its one-rank form is checked in
+    test_rccl_communicator_single_rank.)"""
+    import threading
+    comms = slab_mod.loopback_comms(4)
+    got, errors = [None] * 4, []
+
+    def work(r):
+        try:
+            got[r] = comms[r].gather_info()
+        except Exception as err:   # noqa: BLE001 -- reported below
+            errors.append(err)
+
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert all(g == got[0] for g in got)
+    assert [g["rank"] for g in got[0]] == [0, 1, 2, 3] and all(g["ranks"] == 4 for g in got[0])
+    assert len({g["pci_bus_id"] for g in got[0]}) == 1      # one GPU here: bench.py would refuse this as a real job
+    assert comms[2].info()["kind"] == "loopback"
+    for c in comms:
+        c.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("world", [2, 4])
 def test_slabs_match_undivided_system_device(device, world):
     moved = check(device, 40000, world, 6, 0.004, device="hip")
