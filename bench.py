@@ -78,6 +78,9 @@ MODELS = {
                        "(examples/branching.cu, 7-float cells)"),
 }
 STATE_MODELS = ("passive_growth_grid", "branching_grid")
+# models bench.py can cut into z-slabs: float3 points, nothing indexed by cell id but the cell itself
+# (sorting_grid's functor reads the GLOBAL id: `i < n_cells / 2`, examples/sorting.cu:24)
+SLAB_MODELS = ("springs_grid", "clipped_grid", "relu_grid", "sorting_grid")
 
 
 STATELESS_MODELS = ("springs_grid", "clipped_grid", "sorting_grid", "relu_grid", "relu_po_grid", "relu_cell_grid",
@@ -368,9 +371,10 @@ def main(argv=None):
     n_floats, kernel_name, workload = MODELS[args.model]
     if slab_path:
         ignored = []
-        if args.model != "springs_grid":
-            sys.exit("bench.py: the z-slab path runs springs_grid only (functors of the other "
-                     "models index per-cell arrays by id); drop --model or run on one GPU")
+        if args.model not in SLAB_MODELS:
+            sys.exit("bench.py: the z-slab path runs %s (float3 models without per-cell model arrays or links: "
+                     "those would have to be replicated / migrated by the model); drop --model or run on one GPU"
+                     % ", ".join(SLAB_MODELS))
         if args.sorted_pipeline != 1:
             ignored.append("--sorted-pipeline")
         if args.graph == 1:
@@ -543,11 +547,13 @@ def main(argv=None):
         with Solution("springs_tile", n_total) as whole:
             whole.random_sphere(args.dist, 42)
             X0 = whole.h_X[:n_total].copy()
-        my_slab = slab_mod.Slab("springs_grid", X0, rank, world, gs, cube_size=1.0, lib=engine,
-                                global_ids=False)  # spring only compares i with j
+        my_slab = slab_mod.Slab(args.model, X0, rank, world, gs, cube_size=1.0, lib=engine,
+                                global_ids=args.model == "sorting_grid")  # the others only compare i with j
         del X0
         sim = my_slab.sim
         sim.set_param("force_variant", args.force_variant)
+        if args.model == "sorting_grid":
+            sim.set_param("n_cells", n_total)   # types split at the GLOBAL id n / 2
         if native_rccl:
             my_slab.use(comm=native_comm)
         else:
@@ -651,9 +657,11 @@ def main(argv=None):
     if slab_path and world > 1 and not args.no_one_gpu_reference:
         if rank == 0:
             my_slab.close()
-            with Solution("springs_grid", n_total, gs, 1.0) as whole:
+            with Solution(args.model, n_total, gs, 1.0) as whole:
                 whole.random_sphere(args.dist, 42)
                 whole.set_param("force_variant", args.force_variant)
+                if args.model == "sorting_grid":
+                    whole.set_param("n_cells", n_total)
                 whole.take_step(dt, args.warmup)
                 whole.synchronize()
                 t1 = time.perf_counter()

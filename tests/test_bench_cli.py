@@ -107,3 +107,21 @@ def test_headline_line_carries_the_sustained_figure_and_untimed_events(device):
     r = out["roofline"]
     assert r["timed_launches"] == 2 * 5 and "fresh copy" in r["events_pass"]
     assert r["achieved"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+
+
+@pytest.mark.gpu
+def test_slab_path_runs_the_id_indexed_sorting_model(device):
+    """bench.py's z-slab path is not springs-only (missing 3): sorting_grid, whose functor reads the
+    GLOBAL id of both cells, in two slabs on one GPU (gloo rehearsal transport)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["YALLA_BENCH_DEVICE"] = "0"
+    proc = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--backend", "gloo", "--model", "sorting_grid",
+                           "--steps", "4", "--warmup", "1", "--cells-total", "60000", "--dt", "0.002",
+                           "--migrate-every", "2"], capture_output=True, text=True, timeout=900, env=env)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    out = json.loads([l for l in proc.stdout.splitlines() if l.strip()][-1])
+    assert out["n_gpus"] == 2 and out["config"]["model"] == "sorting_grid" and out["value"] > 0
+    assert out["one_gpu_same_system"] > 0
+    refused = subprocess.run([sys.executable, BENCH, "--slab", "--model", "passive_growth_grid", "--steps", "1"],
+                             capture_output=True, text=True, timeout=300)
+    assert refused.returncode != 0 and "z-slab path runs" in refused.stderr
