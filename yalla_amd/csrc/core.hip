@@ -159,7 +159,6 @@ __global__ __launch_bounds__(BLOCK) void k_scan(int* __restrict__ count,
     __shared__ int sh[4];
     __shared__ int sh_wave[4];
     const int tile = first_tile + blockIdx.x;
-    const unsigned long long epoch = *d_epoch;  // (the last scan's last block left it; a kernel boundary lies between)
 
     size_t base = (size_t)tile * SCAN_TILE + (size_t)threadIdx.x * SCAN_ITEMS;
     int4* c4 = reinterpret_cast<int4*>(count + base);
@@ -176,7 +175,13 @@ __global__ __launch_bounds__(BLOCK) void k_scan(int* __restrict__ count,
         if (lane >= o) incl += up;
     }
     if (lane == 63) sh_wave[w] = incl;
+    // The epoch is read by thread 0 BEFORE the barrier behind which it publishes, and handed to the block through
+    // LDS: the launch's last block moves the epoch on once it has seen every block's word, so no thread may be
+    // left to read it from memory after its own block has published.
+    __shared__ unsigned sh_epoch;
+    if (threadIdx.x == 0) sh_epoch = *d_epoch;  // (written by the last scan: a kernel boundary lies between)
     __syncthreads();
+    const unsigned long long epoch = sh_epoch;
     if (threadIdx.x == 0)
         __hip_atomic_store(&tile_state[tile],
             (epoch << 32) | (unsigned)(sh_wave[0] + sh_wave[1] + sh_wave[2] + sh_wave[3]), __ATOMIC_RELAXED,
