@@ -2380,10 +2380,14 @@ protected:
             sorted_step<pw_int, pw_friction>(n, dt);
             return;
         }
-        if (sorted_path) {
+        if (Computer<Pt>::use_sorted_pipeline()) {
             // The reference reads n first (solvers.cuh:229) and so must we, model kernels
             // change it between steps; but the round trip is hidden behind the binning
             // kernels of the first grid build, which read the count on the device.
+            // (Round 5: with generic forces too.  They need n on the host -- gen_forces(n, d_X, d_dX) -- but
+            // the first build reads d_X only and the generic forces write d_dX only, so the build's first
+            // three kernels may run before them: the device works while the count travels, instead of
+            // standing idle between two steps.)
             YA_CHECK(ya_n_read_begin(n_reader, d_n, nullptr));
             Computer<Pt>::begin_build(d_X, d_n, n_max);
             YA_CHECK(ya_n_read_end(n_reader, &n));
