@@ -5,11 +5,10 @@
 # box).  They are the strongest drop-in check there is: ya||a's tests, our
 # engine.  No reference source is copied: a scratch tree of symlinks makes the
 # tests' `#include "../include/x.cuh"` resolve to include/ of this repo.
-#   test_dtypes test_solvers test_links test_inits test_vtk   -> built
-#   test_polarity  stale in the reference itself   -> skipped
-#   test_mesh      needs mesh.cuh (out of scope)               -> skipped
+#   test_dtypes test_solvers test_links test_inits test_vtk test_mesh   -> built
+#   test_polarity  stale in the reference itself             -> skipped
 # and the reference's model programs (examples/*.cu, unmodified too: the four BASELINE
-# configurations' and the other 15 that compile) into oracle/_ref/examples/.
+# configurations' and the other 18 that compile) into oracle/_ref/examples/.
 set -e
 REF=${REF:-/root/reference}
 HERE=$(cd "$(dirname "$0")" && pwd)
@@ -22,7 +21,7 @@ mkdir -p "$OUT" "$TREE/tests"
 ln -s "$ROOT/include" "$TREE/include"
 for f in "$REF"/tests/*; do ln -s "$f" "$TREE/tests/"; done
 cd "$TREE/tests"
-for t in test_dtypes test_solvers test_links test_inits test_vtk; do
+for t in test_dtypes test_solvers test_links test_inits test_vtk test_mesh; do
   /opt/rocm/bin/hipcc -x hip --offload-arch=gfx950 -std=c++17 -O2 -ffp-contract=off -fno-slp-vectorize \
       -Wno-error=parentheses -w -include "$ROOT/include/compat/cuda_names.h" -I"$ROOT/include/compat" \
       $t.cu -L"$ROOT/yalla_amd" -lyalla_hip -Wl,-rpath,'$ORIGIN/../../yalla_amd' -o "$OUT/$t"
@@ -39,12 +38,12 @@ build_model() {
 }
 export -f build_model
 export ROOT OUT
-# the four BASELINE configurations' programs, then the other 15 that compile (not built:
-# polarization.cu, a reference bug; three models that need mesh.cuh)
+# the four BASELINE configurations' programs, then the other 18 that compile (not built:
+# polarization.cu, a reference bug)
 printf "%s\n" springs sorting passive_growth branching apical_constriction bending epithelia_double_polarity \
     epithelium gradient growth_w_wall intercalation lineage_tracing migration random_walk sorting_prot turing \
-    turing_w_noise wnt write_vtk_w_mask | xargs -P 6 -I{} bash -c 'build_model {}'
-[ "$(ls "$OUT/examples" | wc -l)" -ge 19 ] || { echo "some example programs failed to build"; exit 1; }
+    turing_w_noise wnt write_vtk_w_mask teapot intercalation_w_gradient model_features_sequential_addition | xargs -P 6 -I{} bash -c 'build_model {}'
+[ "$(ls "$OUT/examples" | wc -l)" -ge 22 ] || { echo "some example programs failed to build"; exit 1; }
 # What must be present on the GPU box: the tests FAIL (not skip) there when a listed binary is missing.
 ( cd "$OUT" && { ls test_* | sed 's|^|oracle/_ref/|'; ls examples/* | sed 's|^|oracle/_ref/|'; } ) > "$HERE/ref_manifest.txt"
 echo "wrote oracle/ref_manifest.txt ($(wc -l < "$HERE/ref_manifest.txt") binaries)"

@@ -10,11 +10,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NATIVE = os.path.join(ROOT, "tests", "native")
 
 
-def run(name, marker):
+def run(name, marker, args=(), cwd=None):
     exe = os.path.join(NATIVE, name)
     if not os.path.exists(exe):
         subprocess.run(["make", "-C", NATIVE, name], check=True, capture_output=True)
-    proc = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    proc = subprocess.run([exe, *args], capture_output=True, text=True, timeout=300, cwd=cwd)
     assert proc.returncode == 0 and marker in proc.stdout, proc.stdout[-2000:] + proc.stderr[-2000:]
 
 
@@ -87,6 +87,17 @@ def test_arrays_registered_once_are_kept_in_cube_order():
     renumber call in its loop -- a Property read by id inside the functor, Links, a plain device array and
     cells appended between steps: bit for bit what renumbering by hand every third step gives."""
     run("test_keep_order", "ALL KEEP-ORDER TESTS PASSED")
+
+
+@pytest.mark.gpu
+def test_mesh_header_on_the_device(tmp_path):
+    """include/mesh.cuh (reference mesh.cuh:1-462): nearest-partner distances in slices and wavefront shares
+    against a host loop bit for bit (empty sets, one workgroup, 70 001 partners, float3 against Po_cell), the
+    reference-named kernel at the reference's launch shape, shape comparison between Solutions and against a
+    mesh, and a generated torus written, read back, copied, assigned and rotated."""
+    from mesh_fixtures import write_torus
+    write_torus(tmp_path / "torus.vtk")
+    run("test_mesh_device", "ALL MESH TESTS PASSED", args=[str(tmp_path / "torus.vtk")], cwd=tmp_path)
 
 
 @pytest.mark.gpu

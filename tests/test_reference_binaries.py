@@ -97,3 +97,16 @@ def test_reference_test_inits_unlucky_seed_is_the_tests_statistics(tmp_path, ora
 @pytest.mark.gpu
 def test_reference_test_vtk(tmp_path):
     run("test_vtk", tmp_path, 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 2])
+def test_reference_test_mesh(tmp_path, seed):
+    """tests/test_mesh.cu, 4 cases: extent under translate / rotate / rescale / grow_normally, 1500 points in
+    and out of the surface by ray casting against the analytic distance from the ring, shape comparison 0 and
+    0.1 after growing, copies.  It loads `tests/torus.vtk` from its working directory: a torus of ring radius 1
+    and tube radius 0.5 GENERATED here (tests/mesh_fixtures.py; not the reference's file)."""
+    from mesh_fixtures import write_torus
+    (tmp_path / "tests").mkdir()
+    write_torus(tmp_path / "tests" / "torus.vtk")
+    run("test_mesh", tmp_path, 4, seed=seed)

@@ -112,17 +112,51 @@ def test_branching(tmp_path):
 
 OTHER_MODELS = ["apical_constriction", "bending", "epithelia_double_polarity", "epithelium", "gradient",
                 "growth_w_wall", "intercalation", "lineage_tracing", "migration", "random_walk",
-                "sorting_prot", "turing", "turing_w_noise", "wnt", "write_vtk_w_mask"]
+                "sorting_prot", "turing", "turing_w_noise", "wnt", "write_vtk_w_mask",
+                "model_features_sequential_addition", "intercalation_w_gradient"]
 
 
 @pytest.mark.parametrize("name", OTHER_MODELS)
 def test_other_example_programs_run(tmp_path, name):
-    """The other 15 reference examples that compile (polarity models, Gabriel solver + walls,
+    """The other reference examples that compile (polarity models, Gabriel solver + walls,
     links / protrusions, lineage tracing, Turing patterns with noise, masks): each runs to
-    completion and its last frame holds finite positions."""
+    completion and its last frame holds finite positions.  intercalation_w_gradient.cu loads its initial
+    condition from examples/sphere_ic.vtk: a ball of cells generated here (tests/mesh_fixtures.py)."""
+    if name == "intercalation_w_gradient":
+        from mesh_fixtures import write_sphere_ic
+        (tmp_path / "examples").mkdir()
+        write_sphere_ic(tmp_path / "examples" / "sphere_ic.vtk")
     frames = run_model(name, tmp_path)
     assert len(frames) >= 1
     numbered = sorted((f for f in frames if f.endswith(".vtk")),
                       key=lambda f: (f.rsplit("_", 1)[0], int(f.rsplit("_", 1)[1][:-4])))
     last = read_frame(tmp_path / "output" / numbered[-1])
     assert len(last["points"]) > 0 and np.isfinite(last["points"]).all()
+
+
+def test_teapot_cut_out_of_a_cuboid(tmp_path):
+    """examples/teapot.cu: a cuboid of 70 000 random points, those outside a closed mesh removed
+    (Mesh::test_exclusion under thrust::remove_if on the host).  The program loads `examples/teapot.vtk`; here
+    that file is the generated torus (tests/mesh_fixtures.py), so what must remain is known: the points whose
+    distance from the ring is below the tube radius, give or take the polyhedron's sagitta."""
+    from mesh_fixtures import write_torus
+    (tmp_path / "examples").mkdir()
+    write_torus(tmp_path / "examples" / "teapot.vtk")
+    frames = run_model("teapot", tmp_path)
+    assert frames == ["teapot_0.vtk", "teapot_1.vtk"]
+    before = read_frame(tmp_path / "output" / "teapot_0.vtk")["points"]
+    after = read_frame(tmp_path / "output" / "teapot_1.vtk")["points"]
+
+    def from_ring(p):
+        return np.sqrt((1 - np.hypot(p[:, 0], p[:, 1])) ** 2 + p[:, 2] ** 2)
+
+    assert len(before) > 5000 and np.abs(before).max() <= 1.5 + 1e-6
+    inside = from_ring(before) < 0.5
+    assert 0.2 < inside.mean() < 0.7
+    assert from_ring(after).max() < 0.5 + 1e-3            # nothing outside survived
+    clearly_inside = (from_ring(before) < 0.49).sum()       # the polyhedron lies < 0.005 inside the torus
+    assert clearly_inside <= len(after) <= inside.sum()
+    # the survivors are the inside points of the first frame, in their order (remove_if is stable)
+    kept = before[from_ring(before) < 0.5 - 0.006]
+    it = iter(map(tuple, after))
+    assert all(any(tuple(row) == other for other in it) for row in kept[:200])
