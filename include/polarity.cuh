@@ -13,6 +13,8 @@
 
 #include <math.h>
 
+#include <type_traits>
+
 #ifndef YA_ORACLE
 #include "utils.cuh"  // dot_product
 #endif
@@ -77,6 +79,42 @@ __device__ __host__ Pt bidirectional_polarization_force(Pt Xi, Polarity p)
 {
     const float prod = pol_dot_product<Pt, theta, phi>(Xi, p);
     return prod * unidirectional_polarization_force<Pt, theta, phi>(Xi, p);
+}
+
+// The spelling the reference's own tests/test_polarity.cu:25,43,65-71 and examples/polarization.cu:29 still
+// use (they predate `Polarity`): the partner given as a whole point, of which only the polarity
+// fields count.  Pinned by that test's known answer: bidirectional_polarization_force(i, j).theta = 0.126,
+// .phi = 0.215 for the two Po_cells at test_polarity.cu:22-23.
+namespace ya {
+template<typename Pb>
+struct Whole_point {  // any point type but Polarity itself, which the functions above take
+    static constexpr bool value = !std::is_same<Pb, Polarity>::value;
+};
+template<typename Pb>
+__device__ __host__ Polarity polarity_of(const Pb& b)
+{
+    return Polarity{b.theta, b.phi};
+}
+}  // namespace ya
+
+template<typename Pa, typename Pb>
+__device__ __host__ typename std::enable_if<ya::Whole_point<Pb>::value, float>::type pol_dot_product(Pa a, Pb b)
+{
+    return pol_dot_product(a, ya::polarity_of(b));
+}
+
+template<typename Pt, typename Pb>
+__device__ __host__ typename std::enable_if<ya::Whole_point<Pb>::value, Pt>::type unidirectional_polarization_force(
+    Pt Xi, Pb Xj)
+{
+    return unidirectional_polarization_force(Xi, ya::polarity_of(Xj));
+}
+
+template<typename Pt, typename Pb>
+__device__ __host__ typename std::enable_if<ya::Whole_point<Pb>::value, Pt>::type bidirectional_polarization_force(
+    Pt Xi, Pb Xj)
+{
+    return bidirectional_polarization_force(Xi, ya::polarity_of(Xj));
 }
 
 namespace ya {

@@ -8,7 +8,7 @@
 #   test_dtypes test_solvers test_links test_inits test_vtk test_mesh   -> built
 #   test_polarity  stale in the reference itself             -> skipped
 # and the reference's model programs (examples/*.cu, unmodified too: the four BASELINE
-# configurations' and the other 18 that compile) into oracle/_ref/examples/.
+# configurations' and the other 19) into oracle/_ref/examples/.
 set -e
 REF=${REF:-/root/reference}
 HERE=$(cd "$(dirname "$0")" && pwd)
@@ -38,12 +38,13 @@ build_model() {
 }
 export -f build_model
 export ROOT OUT
-# the four BASELINE configurations' programs, then the other 18 that compile (not built:
-# polarization.cu, a reference bug)
+# the four BASELINE configurations' programs, then the other 19 (polarization.cu calls
+# bidirectional_polarization_force with a whole point for the partner, the spelling before `Polarity`,
+# include/polarity.cuh keeps that overload)
 printf "%s\n" springs sorting passive_growth branching apical_constriction bending epithelia_double_polarity \
     epithelium gradient growth_w_wall intercalation lineage_tracing migration random_walk sorting_prot turing \
-    turing_w_noise wnt write_vtk_w_mask teapot intercalation_w_gradient model_features_sequential_addition | xargs -P 6 -I{} bash -c 'build_model {}'
-[ "$(ls "$OUT/examples" | wc -l)" -ge 22 ] || { echo "some example programs failed to build"; exit 1; }
+    turing_w_noise wnt write_vtk_w_mask teapot intercalation_w_gradient model_features_sequential_addition polarization | xargs -P 6 -I{} bash -c 'build_model {}'
+[ "$(ls "$OUT/examples" | wc -l)" -ge 23 ] || { echo "some example programs failed to build"; exit 1; }
 # What must be present on the GPU box: the tests FAIL (not skip) there when a listed binary is missing.
 ( cd "$OUT" && { ls test_* | sed 's|^|oracle/_ref/|'; ls examples/* | sed 's|^|oracle/_ref/|'; } ) > "$HERE/ref_manifest.txt"
 echo "wrote oracle/ref_manifest.txt ($(wc -l < "$HERE/ref_manifest.txt") binaries)"

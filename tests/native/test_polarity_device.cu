@@ -9,9 +9,11 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 
 struct Results {
-    Po_cell polarization, bending, migration_i, migration_j, apical;
+    Po_cell polarization, polarization_whole_point, aligning_whole_point, bending, migration_i, migration_j, apical;
+    float dot_whole_point, dot_polarity;
     Polarity inverse;
     float3 normal;
 };
@@ -22,6 +24,12 @@ __host__ __device__ void evaluate(Results* out)
         Po_cell i{0.601f, 0.305f, 0.320f, 0.209f, 0.295f};
         Polarity j{0.340f, 0.431f};
         out->polarization = bidirectional_polarization_force(i, j);
+        // the partner as a whole point, as tests/test_polarity.cu:22-25 and examples/polarization.cu:29 write it
+        Po_cell whole{0.762f, 0.403f, 0.121f, 0.340f, 0.431f};
+        out->polarization_whole_point = bidirectional_polarization_force(i, whole);
+        out->aligning_whole_point = unidirectional_polarization_force(i, whole) - unidirectional_polarization_force(i, j);
+        out->dot_whole_point = pol_dot_product(j, whole);  // a Polarity against a point (test_polarity.cu:65)
+        out->dot_polarity = pol_dot_product(whole, j);
     }
     Po_cell bi{0.935f, 0.675f, 0.649f, 0.793f, 0.073f}, bj{0.566f, 0.809f, 0.533f, 0.297f, 0.658f};
     {
@@ -71,6 +79,9 @@ int main()
     // the reference's numbers, on the device
     EXPECT(isclose(dev.polarization.x, 0) && isclose(dev.polarization.y, 0) && isclose(dev.polarization.z, 0));
     EXPECT(isclose(dev.polarization.theta, 0.126f) && isclose(dev.polarization.phi, 0.215f));
+    EXPECT(memcmp(&dev.polarization_whole_point, &dev.polarization, sizeof(Po_cell)) == 0);
+    EXPECT(dev.aligning_whole_point.theta == 0 && dev.aligning_whole_point.phi == 0);
+    EXPECT(isclose(dev.dot_whole_point, 1) && dev.dot_whole_point == dev.dot_polarity);
     EXPECT(isclose(dev.bending.x, 0.214f) && isclose(dev.bending.y, -0.971f) && isclose(dev.bending.z, -1.802f));
     EXPECT(isclose(dev.bending.theta, -0.339f) && isclose(dev.bending.phi, 0.453f));
     EXPECT(isclose(dev.migration_i.x, 0.6f) && isclose(dev.migration_i.y, -0.8f) &&

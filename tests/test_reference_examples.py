@@ -113,7 +113,7 @@ def test_branching(tmp_path):
 OTHER_MODELS = ["apical_constriction", "bending", "epithelia_double_polarity", "epithelium", "gradient",
                 "growth_w_wall", "intercalation", "lineage_tracing", "migration", "random_walk",
                 "sorting_prot", "turing", "turing_w_noise", "wnt", "write_vtk_w_mask",
-                "model_features_sequential_addition", "intercalation_w_gradient"]
+                "model_features_sequential_addition", "intercalation_w_gradient", "polarization"]
 
 
 @pytest.mark.parametrize("name", OTHER_MODELS)
