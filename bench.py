@@ -98,7 +98,7 @@ def force_kernel_label(default_name, variant, n, model=""):
         if lanes == 1:
             return default_name
         return default_name.replace("grid_force_bits<", "grid_force_coop<").replace(">", f", {lanes} lanes per cell>")
-    return default_name.replace("grid_force_bits", {0: "grid_force_direct", 1: "grid_force"}[variant])
+    return default_name.replace("grid_force_bits", {0: "grid_force_direct", 1: "grid_force"}.get(variant, f"force_variant_{variant}"))
 
 
 def force_bytes_per_cell(n_floats):

@@ -306,4 +306,154 @@ __global__ __launch_bounds__(bits::BLOCK) void grid_force_persistent(const int n
     }
 }
 
+// EXPERIMENT (variant 8): ONE hardware-dispatched launch whose first `n_whole` workgroups (a multiple of 8) are
+// whole tiles and whose LAST workgroups are half tiles that meet through memory as in grid_force_halves: only
+// the end of the launch -- the drain, one wavefront lifetime at falling occupancy -- is made of wavefronts that
+// live half as long; the dispatcher's rate (128 workgroups per us) is no limit for the few of them.  A whole
+// tile adds P[dz=0] + P[dz=-1,+1] itself, so every cell's sums are the same whoever computed them.
+template<typename Pt, Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction>
+__global__ __launch_bounds__(bits::BLOCK) void grid_force_mixed(const int n,
+    const Entry<Pt>* __restrict__ sorted, const float4* __restrict__ sorted_v,
+    const int* __restrict__ cube_id, const int* __restrict__ offs, const int gs,
+    const int n_cubes, const float cut2, Pt* __restrict__ d_dX, const bool has_gen,
+    const int n_active, Pt* __restrict__ d_dX_sorted, float* exchange, int* tickets, const int n_tiles, const int n_whole)
+{
+    constexpr int FB = bits::BLOCK;
+    constexpr int CAP = bits::Stage<Pt>::value;
+    constexpr int NF = N_floats<Pt>::value;
+    constexpr int NC = NF + 4;
+    __shared__ __attribute__((aligned(16))) Entry<Pt> sh_e[CAP + 8];
+    __shared__ unsigned sh_m[(bits::WORDS + 1) * FB];
+    __shared__ float4 sh_v[1];
+    __shared__ int sh_second;
+    bits::Lds_word* const words = (bits::Lds_word*)sh_m + threadIdx.x;
+
+    int half = -1, compact = blockIdx.x;
+    if ((int)blockIdx.x >= n_whole) {
+        const int b = blockIdx.x - n_whole;
+#ifdef YA_MIXED_LONG_FIRST
+        // all the longer halves (the cells' own plane: ~63 % of a tile's pairs) first, the shorter ones last
+        const int tail8 = (n_tiles - n_whole + 7) & ~7;
+        half = b >= tail8;
+        compact = n_whole + (half ? b - tail8 : b);
+#else
+        // blocks b and b + 8 are the halves of one tile, both on XCD b % 8
+        half = (b >> 3) & 1;
+        compact = n_whole + (b >> 4) * 8 + (b & 7);
+#endif
+#ifdef YA_MIXED_PRIO
+        __builtin_amdgcn_s_setprio(YA_MIXED_PRIO);
+#endif
+    }
+    if (compact >= n_tiles) return;
+    const int tile = xcd_contiguous_tile(compact, n_tiles);
+    const int s0 = tile * FB;
+    const int s = s0 + threadIdx.x;
+    bool active = s < n;
+    const int c_lo = cube_id[s0];
+    const int c_hi = cube_id[min(s0 + FB, n) - 1];
+
+    Pt Xi = ya::zero<Pt>();
+    int i = 0, c = c_lo;
+    if (active) {
+        const Entry<Pt> self = sorted[s];
+        Xi = self.X;
+        i = self.id;
+        c = cube_id[s];
+        active = i < n_active;
+    }
+    Pt F = ya::zero<Pt>();
+    float3 sum_v{0.f, 0.f, 0.f};
+    float sum_friction = 0;
+    float first[NC];  // a whole tile: the sums of plane dz = 0 while the other two planes are walked
+#pragma unroll
+    for (int k = 0; k < NC; k++) first[k] = 0.f;
+
+    int next_lo[3], next_hi[3], next_begin[3], next_end[3];
+    const int plane_first = half == 1 ? 1 : 0, plane_end = half == 0 ? 1 : 3;
+#pragma unroll 1
+    for (int plane = plane_first; plane < plane_end; plane++) {
+        if (half < 0 && plane == 1) {
+#pragma unroll
+            for (int k = 0; k < NF; k++) first[k] = field(F, k);
+            first[NF] = sum_v.x, first[NF + 1] = sum_v.y, first[NF + 2] = sum_v.z, first[NF + 3] = sum_friction;
+            F = ya::zero<Pt>(), sum_v = float3{0.f, 0.f, 0.f}, sum_friction = 0;
+        }
+        int wg_begin[3], v0[4], k_begin[3], k_end[3];
+        v0[0] = 0;
+        YA_ROW_BOUNDS(plane)
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            wg_begin[r] = next_lo[r];
+            v0[r + 1] = v0[r] + next_hi[r] - wg_begin[r];
+            k_begin[r] = next_begin[r];
+            k_end[r] = active ? next_end[r] : k_begin[r];
+        }
+        const int total = v0[3];
+        for (int chunk = 0; chunk < total; chunk += CAP) {
+            const int chunk_n = min(CAP, total - chunk);
+            __syncthreads();
+            for (int t = threadIdx.x; t < chunk_n; t += FB) {
+                const int v = chunk + t;
+                const int shift = v >= v0[2] ? wg_begin[2] - v0[2]
+                                             : (v >= v0[1] ? wg_begin[1] - v0[1] : wg_begin[0]);
+                sh_e[t] = sorted[v + shift];
+            }
+            __syncthreads();
+            int sb[3], se[3], shift[3];
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                sb[r] = max(k_begin[r] - wg_begin[r] + v0[r], chunk) - chunk;
+                se[r] = min(k_end[r] - wg_begin[r] + v0[r], chunk + chunk_n) - chunk;
+                shift[r] = wg_begin[r] - v0[r] + chunk;
+            }
+            const int bits_needed = (max(se[0] - sb[0], 0) + 3 & ~3) + (max(se[1] - sb[1], 0) + 3 & ~3) +
+                                    (max(se[2] - sb[2], 0) + 3 & ~3);
+            if (!__any(bits_needed > bits::PASS_BITS)) {
+                bits::pass<Pt, pw_int, pw_friction, false, false>(sh_e, sh_v, words, sb[0], se[0], sb[1], se[1], sb[2],
+                    se[2], shift[0], shift[1], shift[2], sorted_v, Xi, i, cut2, F, sum_v, sum_friction, nullptr);
+            } else {
+#pragma unroll 1
+                for (int r = 0; r < 3; r++) {
+                    const int rb = r == 0 ? sb[0] : (r == 1 ? sb[1] : sb[2]);
+                    const int re = r == 0 ? se[0] : (r == 1 ? se[1] : se[2]);
+                    const int rs = r == 0 ? shift[0] : (r == 1 ? shift[1] : shift[2]);
+#pragma unroll 1
+                    for (int b = rb; __any(b < re); b += bits::PASS_BITS)
+                        bits::pass<Pt, pw_int, pw_friction, false, false>(sh_e, sh_v, words, b, min(re, b + bits::PASS_BITS),
+                            0, 0, 0, 0, rs, 0, 0, sorted_v, Xi, i, cut2, F, sum_v, sum_friction, nullptr);
+                }
+            }
+        }
+    }
+    float part[NC];
+#pragma unroll
+    for (int k = 0; k < NF; k++) part[k] = field(F, k);
+    part[NF] = sum_v.x, part[NF + 1] = sum_v.y, part[NF + 2] = sum_v.z, part[NF + 3] = sum_friction;
+    if (half < 0) {
+#pragma unroll
+        for (int k = 0; k < NC; k++) part[k] = first[k] + part[k];  // P[dz=0] + P[dz=-1,+1]
+    } else {
+        float* const mine = exchange + ((size_t)tile * 2 + half) * NC * FB + threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < NC; k++) __hip_atomic_store(mine + k * FB, part[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        if (threadIdx.x == 0) sh_second = __hip_atomic_fetch_add(&tickets[tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (sh_second == 0) return;  // the other half will finish the tile
+        if (threadIdx.x == 0) __hip_atomic_store(&tickets[tile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float* const theirs = exchange + ((size_t)tile * 2 + (1 - half)) * NC * FB + threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < NC; k++)
+            part[k] = part[k] + __hip_atomic_load(theirs + k * FB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (active) {
+#pragma unroll
+        for (int k = 0; k < NF; k++) field(F, k) = part[k];
+        const Pt dX = store_rhs(d_dX, i, has_gen, F, float3{part[NF], part[NF + 1], part[NF + 2]}, part[NF + 3]);
+        if (d_dX_sorted) d_dX_sorted[s] = dX;
+    }
+}
+
 }  // namespace ya

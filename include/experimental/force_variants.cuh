@@ -40,7 +40,16 @@ __global__ __launch_bounds__(FORCE_BLOCK) void grid_force_direct(const int n,
     Pt F = ya::zero<Pt>();
     float3 sum_v{0.f, 0.f, 0.f};
     float sum_friction = 0;
+    // the engine's summation order (grid_force_bits): the own plane's sums (rows 0-2) kept aside, the
+    // other planes' summed from +0, the two added at the end
+    Pt F_own = ya::zero<Pt>();
+    float3 sum_v_own{0.f, 0.f, 0.f};
+    float sum_friction_own = 0;
     for (int row = 0; row < 9; row++) {
+        if (row == 3) {
+            F_own = F, sum_v_own = sum_v, sum_friction_own = sum_friction;
+            F = ya::zero<Pt>(), sum_v = float3{0.f, 0.f, 0.f}, sum_friction = 0;
+        }
         const int mid = c + stencil_row_offset(row, gs);
         // The reference indexes cube_start/end without bounds checks
         // (solvers.cuh:444); out-of-grid cubes are treated as empty here.
@@ -65,7 +74,8 @@ __global__ __launch_bounds__(FORCE_BLOCK) void grid_force_direct(const int n,
             }
         }
     }
-    store_rhs(d_dX, i, has_gen, F, sum_v, sum_friction);
+    store_rhs(d_dX, i, has_gen, F_own + F,
+        float3{sum_v_own.x + sum_v.x, sum_v_own.y + sum_v.y, sum_v_own.z + sum_v.z}, sum_friction_own + sum_friction);
 }
 
 // Cells staged in LDS at a time (16 B per float3 cell) and the per-thread
@@ -161,8 +171,15 @@ __global__ __launch_bounds__(FORCE_BLOCK) void grid_force(const int n,
     int slot0 = 0, slot1 = 0, slot2 = 0;        // the same anchors as slots of the sorted arrays
 
     int next_lo[3], next_hi[3], next_begin[3], next_end[3];
+    Pt F_own = ya::zero<Pt>();  // the engine's summation order: own plane | other planes (grid_force_bits)
+    float3 sum_v_own{0.f, 0.f, 0.f};
+    float sum_friction_own = 0;
     YA_ROW_BOUNDS(0)
     for (int plane = 0; plane < 3; plane++) {
+        if (plane == 1) {  // (the FIFOs are empty at the end of every plane)
+            F_own = F, sum_v_own = sum_v, sum_friction_own = sum_friction;
+            F = ya::zero<Pt>(), sum_v = float3{0.f, 0.f, 0.f}, sum_friction = 0;
+        }
         // The plane's three rows, concatenated: row r occupies [v0[r], v0[r+1]).
         int wg_begin[3], v0[4], k_begin[3], k_end[3];
         v0[0] = 0;
@@ -295,7 +312,8 @@ __global__ __launch_bounds__(FORCE_BLOCK) void grid_force(const int n,
         }
     }
     if (active) {
-        const Pt dX = store_rhs(d_dX, i, has_gen, F, sum_v, sum_friction);
+        const Pt dX = store_rhs(d_dX, i, has_gen, F_own + F,
+            float3{sum_v_own.x + sum_v.x, sum_v_own.y + sum_v.y, sum_v_own.z + sum_v.z}, sum_friction_own + sum_friction);
         if (d_dX_sorted) d_dX_sorted[s] = dX;  // for the sorted-space Euler stage
     }
 }

@@ -880,12 +880,15 @@ __global__ __launch_bounds__(bits::BLOCK, bits::Min_waves<Pt>::value) void grid_
     const Entry<Pt>* __restrict__ sorted, const float4* __restrict__ sorted_v,
     const int* __restrict__ cube_id, const int* __restrict__ offs, const int gs,
     const int n_cubes, const float cut2, Pt* __restrict__ d_dX, const bool has_gen,
-    const int n_active, Pt* __restrict__ d_dX_sorted, const int* __restrict__ global_id,
+    const int n_active, Pt* __restrict__ d_dX_sorted, const int* __restrict__ global_id, const int n_tiles,
+    const int tail, float* tail_exchange, int* tail_tickets,
     const int part = 0, const int part_cube_lo = 0, const int part_cube_hi = 0, const int own_cube_lo = 0,
     const int own_cube_hi = 0x7fffffff)
 {
     constexpr int FB = bits::BLOCK;
     constexpr int CAP = bits::Stage<Pt>::value;
+    constexpr int NF = N_floats<Pt>::value;
+    constexpr int NC = NF + 4;  // sums kept per cell: F (NF), friction * old_v (3), friction
     __shared__ __attribute__((aligned(16))) Entry<Pt> sh_e[CAP + 8];  // slack: whole groups are read
     __shared__ unsigned sh_m[(bits::WORDS + 1) * FB];                // [word][thread], one spare row
     // STAGE_V (small systems, Grid_computer::forces): old_v of the staged cells in LDS as well.
@@ -907,21 +910,45 @@ __global__ __launch_bounds__(bits::BLOCK, bits::Min_waves<Pt>::value) void grid_
     // mirrored cells -> own cells at the lower face and own -> mirrored at the upper one (a tile of
     // mirrored cells costs nothing), and with two ranges the XCDs in the middle of the list got
     // nearly twice the work of those at its ends -- all of them also carry an eighth of part 2.
-    int tile;
+    //
+    // Round 5, THE TAIL: a launch ends with one wavefront lifetime at falling occupancy (16 % of a launch of
+    // 10^6 cells).  The last `tail` tiles of a launch's list are therefore given to TWO one-wavefront
+    // workgroups each -- half 0 the cells' own z-plane (~63 % of the pairs), half 1 the planes below and above
+    // -- that live half as long and meet through memory: the half that finishes first leaves its sums in the
+    // exchange area and draws the tile's ticket, the half that draws the second ticket adds the other's sums
+    // to its own (a + b == b + a bit for bit) and stores the cells' right-hand sides.  A whole tile keeps the
+    // own plane's sums aside and adds them at the end, so every cell's sums are S[dz = 0] + S[dz = -1, +1],
+    // each in the reference's order from +0, whoever computed them: which tiles are split is a scheduling
+    // decision without any effect on results (and the oracle sums in this order).  ONE launch, hardware
+    // dispatch: blocks [0, whole) are whole tiles, blocks whole + 16 g + x and whole + 16 g + 8 + x the halves
+    // of tile whole + 8 g + x, both on XCD x.  (Everything else that was tried to shorten the drain lost:
+    // DESIGN.md section 6, round 5.)
+    int tile, mine, t_first = 0, t_lo = 0, t_hi = 0;
     if (part == 0) {
-        tile = xcd_contiguous_tile(blockIdx.x, gridDim.x);
+        mine = n_tiles;
     } else {
-        const int tiles = gridDim.x;
-        const int t_first = min(offs[min(max(own_cube_lo, 0), n_cubes)] / FB, tiles);
+        const int tiles = n_tiles;
+        t_first = min(offs[min(max(own_cube_lo, 0), n_cubes)] / FB, tiles);
         const int t_end = max(min((offs[min(own_cube_hi, n_cubes)] + FB - 1) / FB, tiles), t_first);
-        const int t_lo = max(min((offs[min(part_cube_lo, n_cubes)] + FB - 1) / FB, t_end), t_first);
-        const int t_hi = max(min(offs[min(part_cube_hi, n_cubes)] / FB, t_end), t_lo);
-        const int mine = part == 1 ? (t_lo - t_first) + (t_end - t_hi) : t_hi - t_lo;
-        if ((int)blockIdx.x >= mine) return;
+        t_lo = max(min((offs[min(part_cube_lo, n_cubes)] + FB - 1) / FB, t_end), t_first);
+        t_hi = max(min(offs[min(part_cube_hi, n_cubes)] / FB, t_end), t_lo);
+        mine = part == 1 ? (t_lo - t_first) + (t_end - t_hi) : t_hi - t_lo;
+    }
+    const int whole = tail > 0 && mine >= 4 * tail ? (mine - tail) & ~7 : mine;
+    int half = -1, compact = blockIdx.x;
+    if (compact >= whole) {
+        const int b = compact - whole;
+        half = (b >> 3) & 1;
+        compact = whole + (b >> 4) * 8 + (b & 7);
+    }
+    if (compact >= mine) return;
+    if (part == 0) {
+        tile = xcd_contiguous_tile(compact, mine);
+    } else {
         // (part 2 as well: in the cap of a ball -- the first and the last slab -- the tiles' cost falls
         // or rises all along the list, and two ranges per XCD, paired for a whole ball's rise and
         // fall, left the XCD with the two dearest ranges 10 % behind)
-        const int t = xcd_contiguous_tile<16>(blockIdx.x, mine);
+        const int t = xcd_contiguous_tile<16>(compact, mine);
         if (part == 1)
             tile = t < t_lo - t_first ? t_first + t : t_hi + (t - (t_lo - t_first));
         else
@@ -950,9 +977,34 @@ __global__ __launch_bounds__(bits::BLOCK, bits::Min_waves<Pt>::value) void grid_
     float3 sum_v{0.f, 0.f, 0.f};
     float sum_friction = 0;
 
+    // a whole tile: the sums of the own plane while the other two planes are walked -- in registers for
+    // three-float points (91 VGPRs: five wavefronts per SIMD as before), in a lane-private LDS column for
+    // wider ones, whose functors leave no registers (relu_w_epithelium: 161 -> 172 VGPRs would cost the third
+    // wavefront per SIMD)
+    constexpr bool OWN_IN_LDS = sizeof(Pt) > 16;
+    __shared__ float sh_own[OWN_IN_LDS ? NC * FB : 1];
+    float own[OWN_IN_LDS ? 1 : NC];
+#pragma unroll
+    for (int k = 0; k < (OWN_IN_LDS ? 1 : NC); k++) own[k] = 0.f;
+
     int next_lo[3], next_hi[3], next_begin[3], next_end[3];
+    const int plane_first = half == 1 ? 1 : 0, plane_end = half == 0 ? 1 : 3;
 #pragma unroll 1
-    for (int plane = 0; plane < 3; plane++) {
+    for (int plane = plane_first; plane < plane_end; plane++) {
+        if (half < 0 && plane == 1) {
+            float save[NC];
+#pragma unroll
+            for (int k = 0; k < NF; k++) save[k] = field(F, k);
+            save[NF] = sum_v.x, save[NF + 1] = sum_v.y, save[NF + 2] = sum_v.z, save[NF + 3] = sum_friction;
+#pragma unroll
+            for (int k = 0; k < NC; k++) {
+                if (OWN_IN_LDS)
+                    sh_own[k * FB + threadIdx.x] = save[k];
+                else
+                    own[OWN_IN_LDS ? 0 : k] = save[k];
+            }
+            F = ya::zero<Pt>(), sum_v = float3{0.f, 0.f, 0.f}, sum_friction = 0;
+        }
         int wg_begin[3], v0[4], k_begin[3], k_end[3];
         v0[0] = 0;
         YA_ROW_BOUNDS(plane)
@@ -1005,8 +1057,43 @@ __global__ __launch_bounds__(bits::BLOCK, bits::Min_waves<Pt>::value) void grid_
             }
         }
     }
+    float sums[NC];
+#pragma unroll
+    for (int k = 0; k < NF; k++) sums[k] = field(F, k);
+    sums[NF] = sum_v.x, sums[NF + 1] = sum_v.y, sums[NF + 2] = sum_v.z, sums[NF + 3] = sum_friction;
+    if (half < 0) {
+#pragma unroll
+        for (int k = 0; k < NC; k++)  // S[dz = 0] + S[dz = -1, +1]
+            sums[k] = (OWN_IN_LDS ? sh_own[k * FB + threadIdx.x] : own[OWN_IN_LDS ? 0 : k]) + sums[k];
+    } else {
+        // Device-scope relaxed atomic stores and loads go past the XCD's L2 without a fence (a device-scope
+        // FENCE would write back and invalidate the whole L2 once per workgroup); the workgroup-scope release
+        // waits until the stores are acknowledged before the ticket is drawn.
+        __shared__ int sh_second;
+        const int slot = compact - whole;
+        float* const mine_out = tail_exchange + ((size_t)slot * 2 + half) * NC * FB + threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < NC; k++)
+            __hip_atomic_store(mine_out + k * FB, sums[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        if (threadIdx.x == 0)
+            sh_second = __hip_atomic_fetch_add(&tail_tickets[slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (sh_second == 0) {  // the other half will finish the tile
+            YA_BITS_PROBE_END(tile)
+            return;
+        }
+        if (threadIdx.x == 0) __hip_atomic_store(&tail_tickets[slot], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float* const theirs = tail_exchange + ((size_t)slot * 2 + (1 - half)) * NC * FB + threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < NC; k++)
+            sums[k] = sums[k] + __hip_atomic_load(theirs + k * FB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (active) {
-        const Pt dX = store_rhs(d_dX, i, has_gen, F, sum_v, sum_friction);
+#pragma unroll
+        for (int k = 0; k < NF; k++) field(F, k) = sums[k];
+        const Pt dX = store_rhs(d_dX, i, has_gen, F, float3{sums[NF], sums[NF + 1], sums[NF + 2]}, sums[NF + 3]);
         if (d_dX_sorted) d_dX_sorted[s] = dX;  // for the sorted-space Euler stage
     }
     YA_BITS_PROBE_END(tile)
@@ -1140,13 +1227,24 @@ __global__ __launch_bounds__(coop::BLOCK) void grid_force_coop(const int n,
     __syncthreads();
 
     float acc[SLOTS];  // this lane's component sums (components lane, lane + LANES, ...)
+    // The engine's summation order (grid_force_bits, "the tail"): the own plane's sums (rows 0-2) are kept
+    // aside and the other planes' summed from +0; the two are added at the end.  A cell's hit list never
+    // mixes the two: listing stops before row 3 until the own plane's list has been worked off.
+    float acc_own[SLOTS];
 #pragma unroll
-    for (int a = 0; a < SLOTS; a++) acc[a] = 0.f;
+    for (int a = 0; a < SLOTS; a++) acc[a] = 0.f, acc_own[a] = 0.f;
+    bool own_done = false;
+#define YA_COOP_OWN_DONE                                          \
+    {                                                             \
+        _Pragma("unroll") for (int a = 0; a < SLOTS; a++) acc_own[a] = acc[a], acc[a] = 0.f; \
+        own_done = true;                                          \
+    }
 
     const int rows_at_once = v0[9] <= CAP ? 9 : 3;
 #pragma unroll 1
     for (int g0 = 0; g0 < 9; g0 += rows_at_once) {
         const int g_end = g0 + rows_at_once;
+        if (g0 == 3) YA_COOP_OWN_DONE  // plane by plane: every list is worked off at the end of a chunk
         const int g_base = g0 == 0 ? 0 : (g0 == 3 ? v0[3] : v0[6]);
         const int g_total = (g_end == 9 ? v0[9] : (g_end == 3 ? v0[3] : v0[6])) - g_base;
 #pragma unroll 1
@@ -1182,8 +1280,9 @@ __global__ __launch_bounds__(coop::BLOCK) void grid_force_coop(const int n,
                 // ---- A: stretches of rows until every cell of the wavefront is through or
                 // its list could overflow ----
                 while (true) {
-                    const int stretch = r < g_end ? min(len - k0, coop::STRETCH) : 0;
-                    const bool go = r < g_end && listed + stretch <= MAX_HITS;
+                    const int row_limit = own_done ? g_end : min(g_end, 3);
+                    const int stretch = r < row_limit ? min(len - k0, coop::STRETCH) : 0;
+                    const bool go = r < row_limit && listed + stretch <= MAX_HITS;
                     if (!__any(go)) break;
                     if (go) {
                         // this lane's share [pb, pe) of the stretch: bit j of the mask, counted
@@ -1233,7 +1332,11 @@ __global__ __launch_bounds__(coop::BLOCK) void grid_force_coop(const int n,
                         }
                     }
                 }
-                if (!__any(listed > 0)) break;  // every cell is through all rows
+                if (!__any(listed > 0)) {
+                    if (!__any(r < g_end)) break;  // every cell is through all rows
+                    if (rows_at_once == 9 && !own_done && r >= 3) YA_COOP_OWN_DONE  // no hit in the own plane's last rows
+                    continue;
+                }
                 coop::wave_sync();
                 // ---- B and C, LANES hits per round.  Lanes past the end of the list leave zero
                 // terms: a sum that starts at +0 never is -0, so adding +0 changes no bit ----
@@ -1284,6 +1387,7 @@ __global__ __launch_bounds__(coop::BLOCK) void grid_force_coop(const int n,
                     coop::wave_sync();
                 }
                 listed = 0;
+                if (rows_at_once == 9 && !own_done && r >= 3) YA_COOP_OWN_DONE
             }
 #undef YA_COOP_ROW
         }
@@ -1291,8 +1395,9 @@ __global__ __launch_bounds__(coop::BLOCK) void grid_force_coop(const int n,
 #pragma unroll
     for (int a = 0; a < SLOTS; a++) {
         const int q = lane + LANES * a;
-        if (q < NC) sh_sum[cell][q] = acc[a];
+        if (q < NC) sh_sum[cell][q] = acc_own[a] + acc[a];
     }
+#undef YA_COOP_OWN_DONE
     coop::wave_sync();
     if (active && lane == 0) {
         Pt F;
@@ -2628,6 +2733,7 @@ public:
         ya_free(d_resorted);
         ya_free(d_resorted_v);
         ya_free(d_dX_sorted);
+        for (int p = 0; p < 3; p++) ya_free(d_tail_exchange[p]), ya_free(d_tail_tickets[p]);
         if (interior_stream && interior_stream_owned) (void)hipStreamDestroy(interior_stream);
         if (grid_built) {
             (void)hipEventDestroy(grid_built);
@@ -2635,12 +2741,21 @@ public:
         }
     }
     Grid_computer(const Grid_computer&) = delete;
+    // grid_force_bits' tail (the last tiles of a launch as half tiles): -1 = chosen from the launch's size,
+    // 0 = none, or the number of tiles (A/B knob).  Results do not depend on it.
+    int force_tail_tiles = -1;
+    float* d_tail_exchange[3] = {nullptr, nullptr, nullptr};  // per launch kind (part 0 / 1 / 2)
+    int* d_tail_tickets[3] = {nullptr, nullptr, nullptr};
+    int tail_room = 0;
 #ifdef YA_EXPERIMENTAL_FORCE_HALVES
     float* d_halves_exchange = nullptr;  // (force_variant 6 / 7, tools/micro/force_ab.hip: never freed before exit)
     int* d_halves_tickets = nullptr;
     int halves_tiles = 0;
     long persistent_launches = 0;
-    int persistent_blocks = 0, persistent_tail_turns = 0;
+#ifndef YA_MIXED_TAIL_DEFAULT
+#define YA_MIXED_TAIL_DEFAULT 0
+#endif
+    int persistent_blocks = 0, persistent_tail_turns = 0, mixed_tail_tiles = YA_MIXED_TAIL_DEFAULT;
 #endif
     bool sorted_pipeline = true;  // false = both stages through d_X / d_X1 (A/B)
     // z-slab decomposition (include/slab_logic.inc): 1 = the next forces() call launches the tiles
@@ -2773,10 +2888,32 @@ protected:
         } else if (force_variant >= 2 && force_variant < 6) {
 #define YA_BITS_LAUNCH(stage_v_, gids_)                                                        \
     YA_FORCE_LAUNCH((ya::grid_force_bits<Pt, pw_int, pw_friction, stage_v_, gids_>),           \
-        (n + ya::bits::BLOCK - 1) / ya::bits::BLOCK, ya::bits::BLOCK, n, d_cells, d_cells_v,   \
+        tiles + (tail > 0 ? tail + 24 : 0), ya::bits::BLOCK, n, d_cells, d_cells_v,            \
         (const int*)grid.d_cube_id, grid.offsets(), grid.grid_size, grid.n_cubes, cut2, d_dX,  \
-        has_gen, n_active, d_dX_in_cell_order, (const int*)d_global_id, part, force_part_cube_lo, \
+        has_gen, n_active, d_dX_in_cell_order, (const int*)d_global_id, tiles, tail,           \
+        d_tail_exchange[part], d_tail_tickets[part], part, force_part_cube_lo,                 \
         force_part_cube_hi, force_own_cube_lo, force_own_cube_hi)
+            const int tiles = (n + ya::bits::BLOCK - 1) / ya::bits::BLOCK;
+            // the end of a launch as half tiles (grid_force_bits, "the tail"): launches that fill the chip
+            // several times over; the kernel leaves a list of fewer than four tails' tiles whole.  Two
+            // wavefronts then call the functor for the same cell i at once: only for functors declared
+            // stateless (YA_STATELESS; relu_w_epithelium's `d_mes_nbs[i] += 1` would lose counts)
+            const int tail = !ya::stateless_pair<Pt, pw_int, pw_friction>() ? 0
+                             : (force_tail_tiles >= 0 ? force_tail_tiles : (tiles >= 6144 ? 768 : 0));
+            if (tail > 0 && (!d_tail_exchange[part] || tail_room < tail)) {
+                // (a solver's launches are stream-ordered except parts 1 and 2 of a slab stage, which have
+                // exchange areas of their own)
+                constexpr int NC = ya::N_floats<Pt>::value + 4;
+                YA_CHECK(ya_device_synchronize());
+                for (int p = 0; p < 3; p++) {
+                    if (d_tail_exchange[p]) ya_free(d_tail_exchange[p]), ya_free(d_tail_tickets[p]);
+                    YA_CHECK(ya_malloc((void**)&d_tail_exchange[p], (size_t)(tail + 8) * 2 * NC * ya::bits::BLOCK * sizeof(float)));
+                    YA_CHECK(ya_malloc((void**)&d_tail_tickets[p], (size_t)(tail + 8) * sizeof(int)));
+                    YA_CHECK(ya_memset_async(d_tail_tickets[p], 0, (size_t)(tail + 8) * sizeof(int), nullptr));
+                }
+                YA_CHECK(ya_device_synchronize());
+                tail_room = tail;
+            }
             const bool stage_v = n <= stage_v_max;
             if (d_global_id) {
                 if (stage_v) {
@@ -2806,6 +2943,24 @@ protected:
             YA_FORCE_LAUNCH((ya::grid_force_halves<Pt, pw_int, pw_friction>), 16 * ((tiles + 7) / 8), ya::bits::BLOCK, n,
                 d_cells, d_cells_v, (const int*)grid.d_cube_id, grid.offsets(), grid.grid_size, grid.n_cubes, cut2, d_dX,
                 has_gen, n_active, d_dX_in_cell_order, d_halves_exchange, d_halves_tickets, tiles);
+        }
+        else if (force_variant == 8) {
+            const int tiles = (n + ya::bits::BLOCK - 1) / ya::bits::BLOCK;
+            constexpr int NC = ya::N_floats<Pt>::value + 4;
+            if (halves_tiles < tiles) {
+                if (d_halves_exchange) ya_free(d_halves_exchange), ya_free(d_halves_tickets);
+                halves_tiles = (grid.n_max + ya::bits::BLOCK - 1) / ya::bits::BLOCK;
+                YA_CHECK(ya_malloc((void**)&d_halves_exchange, (size_t)halves_tiles * 2 * NC * ya::bits::BLOCK * sizeof(float)));
+                YA_CHECK(ya_malloc((void**)&d_halves_tickets, (size_t)halves_tiles * sizeof(int)));
+                YA_CHECK(ya_memset_async(d_halves_tickets, 0, (size_t)halves_tiles * sizeof(int), nullptr));
+                YA_CHECK(ya_device_synchronize());
+            }
+            // the last `mixed_tail_tiles` tiles in dispatch order as halves
+            const int whole = tiles > mixed_tail_tiles ? (tiles - mixed_tail_tiles) & ~7 : 0;
+            YA_FORCE_LAUNCH((ya::grid_force_mixed<Pt, pw_int, pw_friction>), whole + 16 * ((tiles - whole + 7) / 8),
+                ya::bits::BLOCK, n, d_cells, d_cells_v, (const int*)grid.d_cube_id, grid.offsets(), grid.grid_size,
+                grid.n_cubes, cut2, d_dX, has_gen, n_active, d_dX_in_cell_order, d_halves_exchange, d_halves_tickets, tiles,
+                whole);
         }
         else if (force_variant == 7) {
             const int tiles = (n + ya::bits::BLOCK - 1) / ya::bits::BLOCK;

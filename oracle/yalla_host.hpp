@@ -497,7 +497,21 @@ protected:
             memset(&F, 0, sizeof(Pt));
             float3 sum_v{0, 0, 0};
             float sum_friction = 0;
+            // THE ENGINE'S SUMMATION ORDER (not the reference's, whose thread adds all 27 cubes' terms to one
+            // sum, :437-459): the terms of the cell's own z-plane (stencil entries 0-8) and those of the planes
+            // below and above (9-26) are summed separately, each in the reference's order from +0, and the two
+            // sums added -- so that the device may give a tile's planes to two wavefronts.
+            Pt F_own;
+            memset(&F_own, 0, sizeof(Pt));
+            float3 sum_v_own{0, 0, 0};
+            float sum_friction_own = 0;
             for (int j = 0; j < 27; j++) {
+                if (j == 9) {
+                    F_own = F, sum_v_own = sum_v, sum_friction_own = sum_friction;
+                    memset(&F, 0, sizeof(Pt));
+                    sum_v = float3{0, 0, 0};
+                    sum_friction = 0;
+                }
                 int cube = grid.d_cube_id[i] + nhood[j];
                 // The reference reads out of bounds here if a cell sits in the
                 // grid's outermost layer; the oracle treats such cubes as empty.
@@ -517,9 +531,9 @@ protected:
                     sum_v += friction * d_old_v[pk];
                 }
             }
-            d_dX[pi] += F;
-            d_sum_v[pi] = sum_v;
-            d_sum_friction[pi] = sum_friction;
+            d_dX[pi] += F_own + F;
+            d_sum_v[pi] = sum_v_own + sum_v;
+            d_sum_friction[pi] = sum_friction_own + sum_friction;
         }
     }
 };

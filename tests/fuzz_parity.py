@@ -47,8 +47,11 @@ def draw(seed):
     # grid_force_coop with the lanes chosen from n); Tile_solver cases always do (lanes_per_cell 0)
     if model.endswith("_grid") and rng.random() < 0.33:
         variant, lanes = -1, 0
+    # round 5 (drawn after everything else): grid_force_bits with the last 1 ... 20 tiles of its launches as
+    # half tiles in half of the cases (the kernel keeps a list of fewer than four tails whole)
+    tail = int(rng.integers(1, 21)) if rng.random() < 0.5 else 0
     return dict(model=model, n=n, gs=max(gs, 8), cs=cs, dist=dist, seed=int(seed), dt=dt, steps=steps,
-                variant=variant, lanes=lanes if variant == 3 else 0, stage_v=stage_v)
+                variant=variant, lanes=lanes if variant == 3 else 0, stage_v=stage_v, tail=tail)
 
 
 def run_case(oracle, device, c):
@@ -61,6 +64,7 @@ def run_case(oracle, device, c):
                 s.set_param("force_variant", c.get("variant", 2))
                 s.set_param("coop_lanes", c.get("lanes", 0))
                 s.set_param("stage_v_max", 1 << 30 if c.get("stage_v") else 0)
+                s.set_param("tail_tiles", c.get("tail", 0))
             s.random_sphere(c["dist"], c["seed"])
             if lib is oracle and c["model"].endswith("_grid"):
                 # a drawn system may blow up (dense start, large dt) and leave the grid: the oracle

@@ -69,16 +69,19 @@ def test_other_functors_bit_exact(oracle, device, model):
     assert np.array_equal(vo.view(np.uint32), vd.view(np.uint32))
 
 
-# (force_variant, coop_lanes, stage_v_max): grid_force_direct, grid_force, grid_force_bits with
-# old_v from global memory and from LDS, grid_force_coop with 16, 8 and 4 lanes per cell
-FORCE_KERNELS = [(0, 0, 0), (1, 0, 0), (2, 0, 0), (2, 0, 1 << 30), (3, 16, 0), (3, 8, 0), (3, 4, 0)]
+# (force_variant, coop_lanes, stage_v_max[, tail_tiles]): grid_force_direct, grid_force, grid_force_bits with
+# old_v from global memory and from LDS, grid_force_coop with 16, 8 and 4 lanes per cell, and
+# grid_force_bits with the last 40 / 8 tiles of every launch as half tiles that meet through memory
+FORCE_KERNELS = [(0, 0, 0), (1, 0, 0), (2, 0, 0), (2, 0, 1 << 30), (3, 16, 0), (3, 8, 0), (3, 4, 0),
+                 (2, 0, 0, 40), (2, 0, 1 << 30, 8)]
 
 
 def select_kernel(s, kernel):
-    variant, lanes, stage_v_max = kernel
+    variant, lanes, stage_v_max = kernel[:3]
     s.set_param("force_variant", variant)
     s.set_param("coop_lanes", lanes)
     s.set_param("stage_v_max", stage_v_max)
+    s.set_param("tail_tiles", kernel[3] if len(kernel) > 3 else 0)
 
 
 def test_all_force_kernels_agree(oracle, device):
@@ -97,6 +100,20 @@ def test_all_force_kernels_agree(oracle, device):
         res.append(Xd)
     for X in res[1:]:
         assert np.array_equal(res[0].view(np.uint32), X.view(np.uint32))
+
+
+def test_tail_of_half_tiles_at_its_default_size(oracle, device):
+    """450 000 cells are 7032 tiles: the launch ends with 768 tiles as pairs of half-tile workgroups
+    (Grid_computer::forces).  The oracle's bits, and the bits of a launch of whole tiles only."""
+    n = 450000
+    (Xo, vo, _), (Xd, vd, _) = run_both(oracle, device, "springs_grid", n, 64, 1.0, 0.5, 11, 0.001, 1)
+    assert np.array_equal(Xo.view(np.uint32), Xd.view(np.uint32))
+    assert np.array_equal(vo.view(np.uint32), vd.view(np.uint32))
+    with Solution("springs_grid", n, 64, 1.0, lib=device) as s:
+        s.random_sphere(0.5, 11)
+        s.set_param("tail_tiles", 0)
+        s.take_step(0.001, 1)
+        assert np.array_equal(s.positions().view(np.uint32), Xd.view(np.uint32))
 
 
 def test_cooperative_kernel_picks_its_lanes_from_n(oracle, device):

@@ -45,6 +45,9 @@ struct Probe : public Solution<Pt, Grid_solver> {
 #if defined(AB_TAIL_TURNS) && defined(YA_EXPERIMENTAL_FORCE_HALVES)
         this->persistent_tail_turns = AB_TAIL_TURNS;  // variant 7: an XCD's last this-many tiles as halves
 #endif
+#if defined(AB_MIXED_TAIL) && defined(YA_EXPERIMENTAL_FORCE_HALVES)
+        this->mixed_tail_tiles = AB_MIXED_TAIL;  // variant 8: the last this-many tiles of a launch as halves
+#endif
 #if defined(AB_PERSISTENT_BLOCKS) && defined(YA_EXPERIMENTAL_FORCE_HALVES)
         this->persistent_blocks = AB_PERSISTENT_BLOCKS;
 #endif
