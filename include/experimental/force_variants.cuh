@@ -117,7 +117,7 @@ constexpr int QUEUE_DEPTH = YA_QUEUE_DEPTH;
 // kept dense by draining only once per plane (or when a FIFO could overflow):
 // a lane's hit count summed over a plane varies far less across the wavefront
 // than its hit count within one 32-candidate stretch.  Order is preserved
-// (FIFO), so every per-cell sum is accumulated in the reference's order.
+// (FIFO), so every per-cell sum is accumulated in grid_force_bits' order (own plane | other planes).
 template<typename Pt, Pairwise_interaction<Pt> pw_int, Pairwise_friction<Pt> pw_friction>
 __global__ __launch_bounds__(FORCE_BLOCK) void grid_force(const int n,
     const Entry<Pt>* __restrict__ sorted, const float4* __restrict__ sorted_v,

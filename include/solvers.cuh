@@ -20,8 +20,14 @@
 //    16-byte-aligned copy {X, id} (+ old_v) so neighbour reads are contiguous:
 //    the 27 stencil cubes are 9 x-rows of 3 consecutive cube ids, i.e. 9
 //    contiguous slot ranges of the sorted array; they are walked in exactly the
-//    reference's d_nhood order (:472-483) and ascending point id inside a cube,
-//    so every per-cell sum is accumulated in the reference's order.
+//    reference's d_nhood order (:472-483) and ascending point id inside a cube.
+//    THE SUMMATION ORDER (round 5; every grid kernel and the oracle): a cell's
+//    terms from its own z-plane (d_nhood[0..8]) and those from the planes below
+//    and above ([9..26]) are summed separately, each in that order from +0, and
+//    the two sums are added -- where the reference's thread adds all 27 cubes'
+//    terms to one sum (:437-459).  It lets grid_force_bits give a tile's planes
+//    to two wavefronts where that shortens a launch ("the tail"); ~1e-7 relative
+//    per step beside the reference's association.
 //  * Tile force: 64-thread (one wavefront) workgroups, 256-point LDS tiles
 //    holding X and old_v, two barriers per tile (the reference's single barrier
 //    at :302 is only safe for a 32-thread block on a 32-wide warp).
@@ -108,7 +114,8 @@ void no_gen_forces(const int n, const Pt* __restrict__ d_X, Pt* d_dX)
 // and the solvers then pick the kernels that share a cell among several lanes whenever the
 // system is too small to fill the chip with one lane per cell (ya::tile_force_coop,
 // ya::grid_force_coop: 2-8 x faster steps below ~10^5 cells, bit-identical results: every sum is
-// still accumulated in the reference's order).  Custom friction functors take
+// still accumulated in the one-lane kernels' order) and split the last tiles of large launches between two
+// wavefronts (grid_force_bits, "the tail").  Custom friction functors take
 // YA_STATELESS_FRICTION; the two defaults are known to be stateless.
 namespace ya {
 template<typename Pt, Pairwise_interaction<Pt> pw_int>
@@ -1123,8 +1130,8 @@ namespace ya {
 //      friction) and leaves the pair's terms {F, friction, friction * old_v} in LDS;
 //   C  ONE lane per component adds the round's terms to that component's sum in list order.
 //
-// Every per-cell sum is therefore accumulated in exactly the reference's order and the result
-// is bit-identical to the kernels above.  What changes is the same as for tile_force_coop: the
+// Every per-cell sum is therefore accumulated in exactly the order of the kernels above (own plane | other
+// planes, each in the reference's order) and the result is bit-identical to theirs.  What changes is the same as for tile_force_coop: the
 // functor is called for one i from several lanes at once, so functors that update per-cell
 // state non-atomically (d_mes_nbs[i] += 1, examples/passive_growth.cu:48-51) must keep one
 // lane per cell.  A, B and C of a cell run inside one wavefront: the only workgroup barriers

@@ -26,6 +26,11 @@
 // (compile with -ffp-contract=off), pair distance = sqrtf(fmaf(z,z,fmaf(y,y,
 // x*x))), division of a Pt by a scalar = multiplication by float(1.0/b)
 // (dtypes.cuh:202-208).
+//
+// ONE deliberate difference in association from the reference (round 5): Grid_computer::pwints sums a cell's
+// terms as S[own z-plane] + S[planes below and above], each partial sum in the reference's stencil order --
+// the engine's documented order, ~1e-7 relative per step beside the reference's single
+// sum.  (The centre-of-mass sum has two documented orders as well: set_reduce_order.)
 #pragma once
 
 #include <assert.h>
