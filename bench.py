@@ -145,6 +145,10 @@ def parse(argv=None):
                          "this many steps; cells must not drift further than an eighth of a cube in between")
     ap.add_argument("--slab", action="store_true",
                     help="use the z-slab path (ghost exchange + all-reduce) even on 1 GPU")
+    ap.add_argument("--tail-tiles", type=int, default=-1,
+                    help="grid_force_bits: the last this-many tiles of a launch as two half-tile workgroups each "
+                         "(-1 = the engine's choice: 768 for launches of 6144 tiles or more, 0 = none); an A/B knob, "
+                         "results do not depend on it")
     ap.add_argument("--force-variant", type=int, default=-1,
                     help="-1 = the engine's choice (default: grid_force_bits, or grid_force_coop below ~1.5e5 cells "
                          "when the model declared its functors stateless), 2 = grid_force_bits always, "
@@ -500,6 +504,8 @@ def main(argv=None):
             sim.random_sphere(args.dist, 42)
         if "grid" in args.model:
             sim.set_param("force_variant", args.force_variant)
+            if args.tail_tiles != -1:
+                sim.set_param("tail_tiles", args.tail_tiles)
             sim.set_param("sorted_pipeline", args.sorted_pipeline)
             if args.graph != 0:
                 sim.set_param("graph", args.graph)
@@ -552,6 +558,8 @@ def main(argv=None):
         del X0
         sim = my_slab.sim
         sim.set_param("force_variant", args.force_variant)
+        if args.tail_tiles != -1:
+            sim.set_param("tail_tiles", args.tail_tiles)
         if args.model == "sorting_grid":
             sim.set_param("n_cells", n_total)   # types split at the GLOBAL id n / 2
         if native_rccl:

@@ -116,6 +116,22 @@ def test_tail_of_half_tiles_at_its_default_size(oracle, device):
         assert np.array_equal(s.positions().view(np.uint32), Xd.view(np.uint32))
 
 
+def test_tail_exchange_over_many_launches(device):
+    """The half tiles' hand-over through memory (relaxed device-scope stores, a ticket, relaxed loads) under
+    load: 10^6 cells, 300 steps = 600 launches x 768 split tiles x 64 cells x 7 sums.  One stale or torn value
+    anywhere would be amplified by the dynamics (friction with the neighbours) into a different trajectory:
+    the positions after 300 steps are bit for bit those of launches made of whole tiles only."""
+    n, out = 1_000_000, []
+    for tail in (-1, 0):
+        with Solution("springs_grid", n, 64, 1.0, lib=device) as s:
+            s.random_sphere(0.5, 5)
+            s.set_param("tail_tiles", tail)
+            s.take_step(0.001, 300)
+            out.append(s.positions())
+    assert np.abs(out[0]).max() < 40 and np.isfinite(out[0]).all()
+    assert np.array_equal(out[0].view(np.uint32), out[1].view(np.uint32))
+
+
 def test_cooperative_kernel_picks_its_lanes_from_n(oracle, device):
     """force_variant 3 with the lanes per cell left to ya::coop::lanes_for: 16, 8 and 4 lanes and,
     above 1.5 * 10^5 cells, the one-lane kernel -- always the oracle's bits."""

@@ -39,6 +39,7 @@ __device__ float3 spring(float3 Xi, float3 r, float dist, int i, int j)  // exam
     if (i == j) return dF;
     return r * (0.5f - dist) / dist;
 }
+YA_STATELESS(float3, spring)  // as the bench's model says of the same functor (yalla_amd/csrc/model_functors.h)
 
 // One empty kernel per rank: launched whenever a slab takes the GPU, so that a kernel trace of
 // this program (rocprofv3 --kernel-trace) can be cut into the slabs' segments
