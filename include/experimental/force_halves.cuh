@@ -114,7 +114,7 @@ __global__ __launch_bounds__(bits::BLOCK) void grid_force_halves(const int n,
     part[NF] = sum_v.x, part[NF + 1] = sum_v.y, part[NF + 2] = sum_v.z, part[NF + 3] = sum_friction;
 #pragma unroll
     for (int k = 0; k < NC; k++) __hip_atomic_store(mine + k * FB, part[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // s_waitcnt: the stores are acknowledged
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the sums are acknowledged at device scope before the ticket is drawn  // s_waitcnt: the stores are acknowledged
     __syncthreads();
     __shared__ int sh_second;
     if (threadIdx.x == 0) sh_second = __hip_atomic_fetch_add(&tickets[tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(bits::BLOCK) void grid_force_persistent(const int n
             float* const mine = exchange + ((size_t)tile * 2 + half) * NC * FB + threadIdx.x;
 #pragma unroll
             for (int k = 0; k < NC; k++) __hip_atomic_store(mine + k * FB, part[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the sums are acknowledged at device scope before the ticket is drawn
             __syncthreads();
             if (threadIdx.x == 0) sh_second = __hip_atomic_fetch_add(&tickets[tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(bits::BLOCK) void grid_force_mixed(const int n,
         float* const mine = exchange + ((size_t)tile * 2 + half) * NC * FB + threadIdx.x;
 #pragma unroll
         for (int k = 0; k < NC; k++) __hip_atomic_store(mine + k * FB, part[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the sums are acknowledged at device scope before the ticket is drawn
         __syncthreads();
         if (threadIdx.x == 0) sh_second = __hip_atomic_fetch_add(&tickets[tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();

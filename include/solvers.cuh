@@ -1073,16 +1073,19 @@ __global__ __launch_bounds__(bits::BLOCK, bits::Min_waves<Pt>::value) void grid_
         for (int k = 0; k < NC; k++)  // S[dz = 0] + S[dz = -1, +1]
             sums[k] = (OWN_IN_LDS ? sh_own[k * FB + threadIdx.x] : own[OWN_IN_LDS ? 0 : k]) + sums[k];
     } else {
-        // Device-scope relaxed atomic stores and loads go past the XCD's L2 without a fence (a device-scope
-        // FENCE would write back and invalidate the whole L2 once per workgroup); the workgroup-scope release
-        // waits until the stores are acknowledged before the ticket is drawn.
+        // Device-scope relaxed atomic stores and loads (sc1) are performed past the XCD's L2, so no fence is
+        // needed for the DATA (a device-scope release fence would write back the whole L2 once per workgroup:
+        // 65 us per 1024 workgroups, core.hip's one-launch reduction).  What orders the sums before the ticket
+        // is the explicit wait: the ticket is drawn only after every store of this wavefront has been
+        // acknowledged at device scope (a workgroup-scope fence and the barrier compile to nothing in a
+        // one-wavefront workgroup, and the stores and the atomic travel to different channels).
         __shared__ int sh_second;
         const int slot = compact - whole;
         float* const mine_out = tail_exchange + ((size_t)slot * 2 + half) * NC * FB + threadIdx.x;
 #pragma unroll
         for (int k = 0; k < NC; k++)
             __hip_atomic_store(mine_out + k * FB, sums[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0)
             sh_second = __hip_atomic_fetch_add(&tail_tickets[slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
