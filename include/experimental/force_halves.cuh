@@ -8,6 +8,8 @@
 // Twice as many wavefronts that live half as long: the drain of a launch (one wavefront lifetime at falling
 // occupancy) is halved without the shared LDS / barrier of a two-wavefront workgroup
 // (profiles/r05_force_ab.jsonl: that form was 8-18 % slower).  Only for functors declared YA_STATELESS.
+// As a WHOLE launch this is 25 % slower (the dispatcher delivers 128 workgroups per us); as the END of a launch
+// of whole tiles it is the shipped kernel's tail (variant 8 below).
 #pragma once
 #ifndef YA_EXPERIMENTAL_FORCE_HALVES
 #error "include/experimental/force_halves.cuh is pulled in by solvers.cuh under -DYA_EXPERIMENTAL_FORCE_HALVES"
@@ -306,7 +308,9 @@ __global__ __launch_bounds__(bits::BLOCK) void grid_force_persistent(const int n
     }
 }
 
-// EXPERIMENT (variant 8): ONE hardware-dispatched launch whose first `n_whole` workgroups (a multiple of 8) are
+// EXPERIMENT (variant 8) -- THE FORM THAT WORKED: grid_force_bits (include/solvers.cuh, "the tail") now does this
+// itself; kept as the kernel the A/B record (profiles/r05_force_ab.jsonl, boxes r05_mixed*) was taken with.
+// ONE hardware-dispatched launch whose first `n_whole` workgroups (a multiple of 8) are
 // whole tiles and whose LAST workgroups are half tiles that meet through memory as in grid_force_halves: only
 // the end of the launch -- the drain, one wavefront lifetime at falling occupancy -- is made of wavefronts that
 // live half as long; the dispatcher's rate (128 workgroups per us) is no limit for the few of them.  A whole
