@@ -94,7 +94,7 @@ def force_kernel_label(default_name, variant, n, model=""):
     if variant == 2 or "grid_force_bits" not in default_name:
         return default_name
     if variant == 3:
-        lanes = 16 if n <= 15000 else 8 if n <= 40000 else 4 if n <= 150000 else 1
+        lanes = 16 if n <= 15000 else 8 if n <= 40000 else 4 if n <= 70000 else 1
         if lanes == 1:
             return default_name
         return default_name.replace("grid_force_bits<", "grid_force_coop<").replace(">", f", {lanes} lanes per cell>")

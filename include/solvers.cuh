@@ -941,7 +941,9 @@ __global__ __launch_bounds__(bits::BLOCK, bits::Min_waves<Pt>::value) void grid_
         t_hi = max(min(offs[min(part_cube_hi, n_cubes)] / FB, t_end), t_lo);
         mine = part == 1 ? (t_lo - t_first) + (t_end - t_hi) : t_hi - t_lo;
     }
-    const int whole = tail > 0 && mine >= 4 * tail ? (mine - tail) & ~7 : mine;
+    // (tail < 0: EVERY tile as halves -- launches whose half tiles are all resident at once, where what
+    // counts is not the drain but the lifetime itself)
+    const int whole = tail < 0 ? 0 : (tail > 0 && mine >= 4 * tail ? (mine - tail) & ~7 : mine);
     int half = -1, compact = blockIdx.x;
     if (compact >= whole) {
         const int b = compact - whole;
@@ -1116,7 +1118,7 @@ __global__ __launch_bounds__(bits::BLOCK, bits::Min_waves<Pt>::value) void grid_
 namespace ya {
 
 // ---------------------------------------------------------------------------------
-// grid_force_coop (the solver's own choice below ~1.5 * 10^5 cells for functors declared YA_STATELESS;
+// grid_force_coop (the solver's own choice below ~7 * 10^4 cells for functors declared YA_STATELESS;
 // forced by Grid_computer::force_variant = 3): the grid force with SEVERAL LANES
 // PER CELL, for systems too small to fill the chip with one lane per cell.  A launch of
 // <= 10^5 cells is at most one wavefront per SIMD for the kernels above, each lane working
@@ -1155,9 +1157,12 @@ struct Stage {
     static constexpr int value = (all_rows ? 9 : 5) * (BLOCK / LANES + 34);
 };
 // Lanes per cell for a launch of n cells (MI355X, springs at rho ~ 10, tools/micro/force_ab.hip:
-// 16 lanes 19 us at 10^4 cells, 8 lanes 24 us at 3 * 10^4, 4 lanes 55 us at 10^5, where one lane
-// per cell takes 53, 64 and 65 us); 1 = one lane per cell is as fast or faster.
-inline int lanes_for(const int n) { return n <= 15000 ? 16 : (n <= 40000 ? 8 : (n <= 150000 ? 4 : 1)); }
+// 16 lanes 19 us at 10^4 cells, 8 lanes 24 us at 3 * 10^4, 4 lanes 39 us at 6.5 * 10^4, where one lane
+// per cell takes 53, 64 and 61 us); 1 = one lane per cell is as fast or faster -- since round 5 that is
+// grid_force_bits with EVERY tile as two half-tile workgroups while all of them are resident at once
+// (Grid_computer::forces): 53 us at 10^5 cells where 4 lanes take 58 (their 1250 workgroups no longer fit
+// the chip in one round from 8 * 10^4 cells on), 63 at 1.5 * 10^5 where they take 79 and whole tiles 71.
+inline int lanes_for(const int n) { return n <= 15000 ? 16 : (n <= 40000 ? 8 : (n <= 70000 ? 4 : 1)); }
 // LDS traffic between the lanes of ONE wavefront: the hardware keeps a wavefront's LDS
 // operations in order, the compiler must too.
 __device__ __forceinline__ void wave_sync()
@@ -2709,11 +2714,11 @@ public:
     ya::Profiler profiler;
     // 2 = grid_force_bits (bit stream) always; 1 = grid_force (byte FIFO), 0 = grid_force_direct: the A/B
     // baselines of include/experimental/force_variants.cuh, only with -DYA_EXPERIMENTAL_FORCE_VARIANTS;
-    // 3 = grid_force_coop below ~1.5 * 10^5 cells (16, 8 or 4 lanes per cell, more the smaller the
+    // 3 = grid_force_coop below ~7 * 10^4 cells (16, 8 or 4 lanes per cell, more the smaller the
     // system), grid_force_bits above: for models whose functors keep no per-cell state without
     // atomics (bit-identical results; see the kernel's comment)
     // -1 (default) = grid_force_bits, or -- for functors declared stateless (YA_STATELESS) --
-    // grid_force_coop below ~1.5 * 10^5 cells
+    // grid_force_coop below ~7 * 10^4 cells
     int force_variant = -1;
     int coop_lanes = 0;            // force_variant 3: 0 = from n (ya::coop::lanes_for), or 4 / 8 / 16
     int stage_v_max = 130000;      // grid_force_bits keeps old_v in LDS too up to this many cells
@@ -2753,10 +2758,23 @@ public:
     Grid_computer(const Grid_computer&) = delete;
     // grid_force_bits' tail (the last tiles of a launch as half tiles): -1 = chosen from the launch's size,
     // 0 = none, or the number of tiles (A/B knob).  Results do not depend on it.
-    int force_tail_tiles = -1;
+    int force_tail_tiles = -1;  // (a number of the launch's tiles or more: every tile as halves)
     float* d_tail_exchange[3] = {nullptr, nullptr, nullptr};  // per launch kind (part 0 / 1 / 2)
     int* d_tail_tickets[3] = {nullptr, nullptr, nullptr};
-    int tail_room = 0;
+    int tail_room[3] = {0, 0, 0};
+    // one-wavefront workgroups of `Kernel` the chip holds at once (occupancy x CUs)
+    template<auto Kernel>
+    static int resident_workgroups()
+    {
+        static const int resident = [] {
+            int per_cu = 0, device = 0, cus = 0;
+            YA_CHECK((int)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, Kernel, ya::bits::BLOCK, 0));
+            YA_CHECK((int)hipGetDevice(&device));
+            YA_CHECK((int)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+            return per_cu * cus;
+        }();
+        return resident;
+    }
 #ifdef YA_EXPERIMENTAL_FORCE_HALVES
     float* d_halves_exchange = nullptr;  // (force_variant 6 / 7, tools/micro/force_ab.hip: never freed before exit)
     int* d_halves_tickets = nullptr;
@@ -2898,33 +2916,43 @@ protected:
         } else if (force_variant >= 2 && force_variant < 6) {
 #define YA_BITS_LAUNCH(stage_v_, gids_)                                                        \
     YA_FORCE_LAUNCH((ya::grid_force_bits<Pt, pw_int, pw_friction, stage_v_, gids_>),           \
-        tiles + (tail > 0 ? tail + 24 : 0), ya::bits::BLOCK, n, d_cells, d_cells_v,            \
-        (const int*)grid.d_cube_id, grid.offsets(), grid.grid_size, grid.n_cubes, cut2, d_dX,  \
+        tail < 0 ? 16 * ((tiles + 7) / 8) : tiles + (tail > 0 ? tail + 24 : 0), ya::bits::BLOCK, n, d_cells, \
+        d_cells_v, (const int*)grid.d_cube_id, grid.offsets(), grid.grid_size, grid.n_cubes, cut2, d_dX,  \
         has_gen, n_active, d_dX_in_cell_order, (const int*)d_global_id, tiles, tail,           \
         d_tail_exchange[part], d_tail_tickets[part], part, force_part_cube_lo,                 \
         force_part_cube_hi, force_own_cube_lo, force_own_cube_hi)
             const int tiles = (n + ya::bits::BLOCK - 1) / ya::bits::BLOCK;
-            // the end of a launch as half tiles (grid_force_bits, "the tail"): launches that fill the chip
-            // several times over; the kernel leaves a list of fewer than four tails' tiles whole.  Two
-            // wavefronts then call the functor for the same cell i at once: only for functors declared
-            // stateless (YA_STATELESS; relu_w_epithelium's `d_mes_nbs[i] += 1` would lose counts)
-            const int tail = !ya::stateless_pair<Pt, pw_int, pw_friction>() ? 0
-                             : (force_tail_tiles >= 0 ? force_tail_tiles : (tiles >= 6144 ? 768 : 0));
-            if (tail > 0 && (!d_tail_exchange[part] || tail_room < tail)) {
+            // Half tiles (grid_force_bits, "the tail"; > 0: the last so many tiles of the launch, < 0: all).
+            // Launches that fill the chip several times over end with 768 tiles as halves (the kernel leaves a
+            // list of fewer than four tails' tiles whole); launches small enough for every half tile to be
+            // resident at once are made of halves altogether.  Two wavefronts then call the functor for the
+            // same cell i at once: only for functors declared stateless (YA_STATELESS; relu_w_epithelium's
+            // `d_mes_nbs[i] += 1` would lose counts).
+            int tail = 0;
+            if (ya::stateless_pair<Pt, pw_int, pw_friction>()) {
+                if (force_tail_tiles >= 0)
+                    tail = force_tail_tiles >= tiles && part == 0 ? -1 : force_tail_tiles;
+                else if (tiles >= 6144)
+                    tail = 768;
+                else if (part == 0 && 2 * tiles <= resident_workgroups<ya::grid_force_bits<Pt, pw_int, pw_friction, false, false>>())
+                    tail = -1;
+            }
+            const int room = tail < 0 ? tiles : tail;
+            if (room > 0 && (!d_tail_exchange[part] || tail_room[part] < room)) {
                 // (a solver's launches are stream-ordered except parts 1 and 2 of a slab stage, which have
                 // exchange areas of their own)
                 constexpr int NC = ya::N_floats<Pt>::value + 4;
                 YA_CHECK(ya_device_synchronize());
-                for (int p = 0; p < 3; p++) {
-                    if (d_tail_exchange[p]) ya_free(d_tail_exchange[p]), ya_free(d_tail_tickets[p]);
-                    YA_CHECK(ya_malloc((void**)&d_tail_exchange[p], (size_t)(tail + 8) * 2 * NC * ya::bits::BLOCK * sizeof(float)));
-                    YA_CHECK(ya_malloc((void**)&d_tail_tickets[p], (size_t)(tail + 8) * sizeof(int)));
-                    YA_CHECK(ya_memset_async(d_tail_tickets[p], 0, (size_t)(tail + 8) * sizeof(int), nullptr));
-                }
+                if (d_tail_exchange[part]) ya_free(d_tail_exchange[part]), ya_free(d_tail_tickets[part]);
+                const size_t slots = (size_t)std::max(room, 768) + 8;
+                YA_CHECK(ya_malloc((void**)&d_tail_exchange[part], slots * 2 * NC * ya::bits::BLOCK * sizeof(float)));
+                YA_CHECK(ya_malloc((void**)&d_tail_tickets[part], slots * sizeof(int)));
+                YA_CHECK(ya_memset_async(d_tail_tickets[part], 0, slots * sizeof(int), nullptr));
                 YA_CHECK(ya_device_synchronize());
-                tail_room = tail;
+                tail_room[part] = (int)slots - 8;
             }
-            const bool stage_v = n <= stage_v_max;
+            // (old_v in LDS costs a launch of halves the residency it lives on: 13 KB per workgroup are 12 per CU)
+            const bool stage_v = n <= stage_v_max && tail >= 0;
             if (d_global_id) {
                 if (stage_v) {
                     YA_BITS_LAUNCH(true, true);

@@ -71,9 +71,9 @@ def test_other_functors_bit_exact(oracle, device, model):
 
 # (force_variant, coop_lanes, stage_v_max[, tail_tiles]): grid_force_direct, grid_force, grid_force_bits with
 # old_v from global memory and from LDS, grid_force_coop with 16, 8 and 4 lanes per cell, and
-# grid_force_bits with the last 40 / 8 tiles of every launch as half tiles that meet through memory
+# grid_force_bits with the last 40 / 8 tiles (or all tiles) of every launch as half tiles that meet through memory
 FORCE_KERNELS = [(0, 0, 0), (1, 0, 0), (2, 0, 0), (2, 0, 1 << 30), (3, 16, 0), (3, 8, 0), (3, 4, 0),
-                 (2, 0, 0, 40), (2, 0, 1 << 30, 8)]
+                 (2, 0, 0, 40), (2, 0, 1 << 30, 8), (2, 0, 0, 1 << 20)]   # the last: EVERY tile as halves
 
 
 def select_kernel(s, kernel):
@@ -133,9 +133,10 @@ def test_tail_exchange_over_many_launches(device):
 
 
 def test_cooperative_kernel_picks_its_lanes_from_n(oracle, device):
-    """force_variant 3 with the lanes per cell left to ya::coop::lanes_for: 16, 8 and 4 lanes and,
-    above 1.5 * 10^5 cells, the one-lane kernel -- always the oracle's bits."""
-    for n, gs in ((9000, 40), (30000, 50), (100000, 64), (160000, 64)):
+    """force_variant 3 with the lanes per cell left to ya::coop::lanes_for: 16, 8 and 4 lanes and, above
+    7 * 10^4 cells, the one-lane kernel -- made of half tiles altogether while they are all resident at once
+    (10^5, 1.6 * 10^5 cells), of whole tiles beyond (2 * 10^5) -- always the oracle's bits."""
+    for n, gs in ((9000, 40), (30000, 50), (60000, 50), (100000, 64), (160000, 64), (200000, 64)):
         (Xo, vo, _), (Xd, vd, _) = run_both(
             oracle, device, "springs_grid", n, gs, 1.0, 0.5, 4, 0.001, 1,
             setup=lambda s: s.set_param("force_variant", 3) if s.lib is device else None)
