@@ -81,7 +81,10 @@ int ya_sim_get_grid(ya_sim* sim, int* cube_id, int* point_id, int* cube_start, i
 int ya_sim_build_grid(ya_sim* sim, int grid_size, float cube_size, int* cube_id, int* point_id,
     int* cube_start, int* cube_end);
 
-/* Model parameters (e.g. "n_cells" for the sorting model). */
+/* Model parameters (e.g. "n_cells" for the sorting model) and the engine's A/B knobs, none of which changes a
+ * result: "force_variant", "coop_lanes", "stage_v_max", "tail_tiles" (grid_force_bits: -1 the engine's choice,
+ * 0 whole tiles only, k the last k tiles of a launch as half tiles, the launch's tile count or more: all),
+ * "sorted_pipeline", "graph", "tile_lanes". */
 int ya_sim_set_param(ya_sim* sim, const char* name, double value);
 /* Integer per-cell properties of a model ("type", "mes_nbs", "epi_nbs"). */
 int ya_sim_set_prop(ya_sim* sim, const char* name, const int* values, int n);
