@@ -1,6 +1,7 @@
 // oracle/yalla_host.hpp -- TEST INFRASTRUCTURE ONLY.  NOT A PRODUCT PATH.
 //
-// Host-serial, single-threaded, plain C++14 restatement of the ya||a hot path
+// Host-serial, single-threaded, plain C++ restatement (built as C++17: the slab sequencing shared with the
+// product, include/slab_logic.inc, uses `if constexpr`) of the ya||a hot path
 //     Solution<Pt, Solver>::take_step<pw_int, pw_friction>(dt, gen_forces)
 // with Tile_solver / Grid_solver, the two-stage Heun update and
 // Links::link_forces.  Every function cites the reference file:line it

@@ -8,7 +8,7 @@ cd "$(dirname "$0")/.."
 make -C oracle > /dev/null
 cp oracle/_build/liboracle_models.so /tmp/oracle_normal.so
 trap 'cp /tmp/oracle_normal.so oracle/_build/liboracle_models.so; touch oracle/_build/liboracle_models.so' EXIT
-g++ -O1 -g -std=c++14 -fPIC -fvisibility=hidden -ffp-contract=off -fno-fast-math -fsanitize=address,undefined \
+g++ -O1 -g -std=c++17 -fPIC -fvisibility=hidden -ffp-contract=off -fno-fast-math -fsanitize=address,undefined \
     -fno-omit-frame-pointer -Ioracle -Iinclude -Iyalla_amd/csrc -shared -Wl,-Bsymbolic \
     -o oracle/_build/liboracle_models.so oracle/oracle_models.cpp
 touch oracle/_build/liboracle_models.so
