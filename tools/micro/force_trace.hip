@@ -1,5 +1,6 @@
 // When and where every workgroup of one grid_force_bits launch ran (include/experimental/force_trace.cuh
-// fills the kernel's probe hooks: s_memtime at entry and exit and the hardware ids): force_trace [cells] [warm steps] > stamps.csv
+// fills the kernel's probe hooks: s_memtime at entry and exit and the hardware ids):
+//   force_trace [cells] [warm steps] [tail tiles: -1 the engine's choice, 0 whole tiles only] > stamps.csv
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -39,7 +40,8 @@ int main(int argc, char** argv)
     Pt *d_out, *d_outs;
     (void)hipMalloc(&d_out, (size_t)n * sizeof(Pt));
     (void)hipMalloc(&d_outs, (size_t)n * sizeof(Pt));
-    const int blocks = (n + 63) / 64;
+    cells.force_tail_tiles = argc > 3 ? atoi(argv[3]) : -1;
+    const int blocks = 2 * ((n + 63) / 64) + 64;  // room for a launch of half tiles; blocks that never ran stay zero
     unsigned long long* d_trace;
     (void)hipMalloc(&d_trace, (size_t)blocks * 4 * sizeof(unsigned long long));
     (void)hipMemset(d_trace, 0, (size_t)blocks * 4 * sizeof(unsigned long long));
@@ -57,10 +59,13 @@ int main(int argc, char** argv)
     (void)hipEventElapsedTime(&ms, e0, e1);
     std::vector<unsigned long long> h((size_t)blocks * 4);
     (void)hipMemcpy(h.data(), d_trace, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-    printf("# cells %d blocks %d launch_us %.1f\n", n, blocks, ms * 1e3f);
+    int stamped = 0;
+    for (int b = 0; b < blocks; b++) stamped += h[4 * b + 1] != 0;
+    printf("# cells %d blocks %d launch_us %.1f tail_tiles %d\n", n, stamped, ms * 1e3f, cells.force_tail_tiles);
     printf("block,t0,t1,hw_id,xcc_id,tile\n");
     for (int b = 0; b < blocks; b++)
-        printf("%d,%llu,%llu,%u,%u,%llu\n", b, h[4 * b], h[4 * b + 1], (unsigned)(h[4 * b + 2] & 0xffffffffu),
+        if (h[4 * b + 1] != 0)
+            printf("%d,%llu,%llu,%u,%u,%llu\n", b, h[4 * b], h[4 * b + 1], (unsigned)(h[4 * b + 2] & 0xffffffffu),
             (unsigned)(h[4 * b + 2] >> 32), h[4 * b + 3]);
     return 0;
 }
