@@ -64,7 +64,12 @@ def test_defaults_follow_north_star():
     assert 14e3 < bench.gather_model_bytes_per_cell_update(3, 0.5) < 17e3
     assert 4e3 < bench.gather_model_bytes_per_cell_update(3, 0.75) < 6e3
     a = bench.parse(["--gpus", "4"])
-    assert a.gpus == 4 and a.cells_total == 0
+    assert a.gpus == 4 and a.cells_total == 0 and a.tail_tiles == -1   # the tail of half tiles: the engine's choice
+    # which force kernel a launch goes to (labels of the bench line): several lanes per cell up to 7e4 cells
+    name = "ya::grid_force_bits<float3, spring, friction_w_neighbour>"
+    assert "16 lanes" in bench.force_kernel_label(name, -1, 10_000, "springs_grid")
+    assert "4 lanes" in bench.force_kernel_label(name, -1, 70_000, "springs_grid")
+    assert bench.force_kernel_label(name, -1, 100_000, "springs_grid") == name
 
 
 @pytest.mark.gpu
