@@ -943,7 +943,9 @@ __global__ __launch_bounds__(bits::BLOCK, bits::Min_waves<Pt>::value) void grid_
     }
     // (tail < 0: EVERY tile as halves -- launches whose half tiles are all resident at once, where what
     // counts is not the drain but the lifetime itself)
-    const int whole = tail < 0 ? 0 : (tail > 0 && mine >= 4 * tail ? (mine - tail) & ~7 : mine);
+    // (the two launches of a slab stage learn their list's length here, not on the host: a list of fewer than
+    // four tails' tiles stays whole)
+    const int whole = tail < 0 ? 0 : (tail > 0 && (part == 0 || mine >= 4 * tail) ? max(mine - tail, 0) & ~7 : mine);
     int half = -1, compact = blockIdx.x;
     if (compact >= whole) {
         const int b = compact - whole;
@@ -2916,26 +2918,29 @@ protected:
         } else if (force_variant >= 2 && force_variant < 6) {
 #define YA_BITS_LAUNCH(stage_v_, gids_)                                                        \
     YA_FORCE_LAUNCH((ya::grid_force_bits<Pt, pw_int, pw_friction, stage_v_, gids_>),           \
-        tail < 0 ? 16 * ((tiles + 7) / 8) : tiles + (tail > 0 ? tail + 24 : 0), ya::bits::BLOCK, n, d_cells, \
+        tail < 0 ? 16 * ((tiles + 7) / 8) : tiles + (tail > 0 ? std::min(tail, tiles) + 24 : 0), ya::bits::BLOCK, n, d_cells, \
         d_cells_v, (const int*)grid.d_cube_id, grid.offsets(), grid.grid_size, grid.n_cubes, cut2, d_dX,  \
         has_gen, n_active, d_dX_in_cell_order, (const int*)d_global_id, tiles, tail,           \
         d_tail_exchange[part], d_tail_tickets[part], part, force_part_cube_lo,                 \
         force_part_cube_hi, force_own_cube_lo, force_own_cube_hi)
             const int tiles = (n + ya::bits::BLOCK - 1) / ya::bits::BLOCK;
             // Half tiles (grid_force_bits, "the tail"; > 0: the last so many tiles of the launch, < 0: all).
-            // Launches that fill the chip several times over end with 768 tiles as halves (the kernel leaves a
-            // list of fewer than four tails' tiles whole); launches small enough for every half tile to be
-            // resident at once are made of halves altogether.  Two wavefronts then call the functor for the
-            // same cell i at once: only for functors declared stateless (YA_STATELESS; relu_w_epithelium's
+            // With R one-wavefront workgroups resident at once (5120 for springs): launches of up to R / 2 tiles
+            // are made of halves altogether; up to R tiles, as many tiles are split as fill the chip in its one
+            // round (R - tiles); beyond, the launch ends with 768 tiles as halves (measured at 2 * 10^5 ...
+            // 10^7 cells, profiles/r05_tail_ab.txt).  Two wavefronts then call the functor for the same cell i
+            // at once: only for functors declared stateless (YA_STATELESS; relu_w_epithelium's
             // `d_mes_nbs[i] += 1` would lose counts).
             int tail = 0;
             if (ya::stateless_pair<Pt, pw_int, pw_friction>()) {
-                if (force_tail_tiles >= 0)
+                if (force_tail_tiles >= 0) {
                     tail = force_tail_tiles >= tiles && part == 0 ? -1 : force_tail_tiles;
-                else if (tiles >= 6144)
-                    tail = 768;
-                else if (part == 0 && 2 * tiles <= resident_workgroups<ya::grid_force_bits<Pt, pw_int, pw_friction, false, false>>())
-                    tail = -1;
+                } else if (part != 0) {
+                    tail = 768;  // (the kernel leaves a list of fewer than four tails' tiles whole)
+                } else {
+                    const int resident = resident_workgroups<ya::grid_force_bits<Pt, pw_int, pw_friction, false, false>>();
+                    tail = 2 * tiles <= resident ? -1 : (tiles <= resident ? resident - tiles : 768);
+                }
             }
             const int room = tail < 0 ? tiles : tail;
             if (room > 0 && (!d_tail_exchange[part] || tail_room[part] < room)) {
