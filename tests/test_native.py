@@ -121,13 +121,21 @@ def test_force_launch_trace(tmp_path):
     if not os.path.exists(exe):
         subprocess.run(["make", "-C", os.path.join(ROOT, "tools"), "micro/ab_bin/force_trace"], check=True,
                        capture_output=True)
-    stamps = tmp_path / "stamps.csv"
-    with open(stamps, "w") as out:
-        subprocess.run([exe, "200000", "3"], stdout=out, check=True, timeout=300)
-    proc = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "force_trace_summary.py"), str(stamps)],
-                          capture_output=True, text=True, check=True)
-    s = json.loads(proc.stdout)
+    def traced(*tail):
+        stamps = tmp_path / "stamps.csv"
+        with open(stamps, "w") as out:
+            subprocess.run([exe, "200000", "3", *tail], stdout=out, check=True, timeout=300)
+        proc = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "force_trace_summary.py"), str(stamps)],
+                              capture_output=True, text=True, check=True)
+        return json.loads(proc.stdout)
+
+    s = traced("0")   # whole tiles only
     assert s["cells"] == 200000 and s["workgroups"] == 3125
     assert s["block_mod_8_is_the_xcd"]
     assert 1 <= s["resident_workgroups_per_cu_max"] <= 24
     assert s["mean_lifetime"] > 0 and sum(s["in_flight"]) > 0
+    # the engine's choice at this size: as many tiles split in two as fill the chip's 5120 wavefront slots in
+    # the launch's one round -- every workgroup still stamped once, the halves of a tile on one XCD
+    split = traced()
+    assert 5100 <= split["workgroups"] <= 5128 and split["block_mod_8_is_the_xcd"]
+    assert split["mean_lifetime"] < s["mean_lifetime"]
