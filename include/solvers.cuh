@@ -2934,12 +2934,13 @@ protected:
             int tail = 0;
             if (ya::stateless_pair<Pt, pw_int, pw_friction>()) {
                 if (force_tail_tiles >= 0) {
-                    tail = force_tail_tiles >= tiles && part == 0 ? -1 : force_tail_tiles;
-                } else if (part != 0) {
-                    tail = 768;  // (the kernel leaves a list of fewer than four tails' tiles whole)
+                    tail = force_tail_tiles >= tiles ? -1 : force_tail_tiles;
                 } else {
                     const int resident = resident_workgroups<ya::grid_force_bits<Pt, pw_int, pw_friction, false, false>>();
-                    tail = 2 * tiles <= resident ? -1 : (tiles <= resident ? resident - tiles : 768);
+                    if (part != 0)  // a slab stage's two launches, side by side: all halves only if both fit at once;
+                        tail = 2 * tiles <= resident ? -1 : 768;  // the kernel leaves a list of < 4 tails' tiles whole
+                    else
+                        tail = 2 * tiles <= resident ? -1 : (tiles <= resident ? resident - tiles : 768);
                 }
             }
             const int room = tail < 0 ? tiles : tail;

@@ -618,7 +618,7 @@ def test_half_tiles_at_the_end_of_both_launches_of_a_stage(device, model):
     in the boundary and the interior launch of a slab stage, which run side by side with exchange areas of
     their own: which tiles are split changes no bit."""
     X0, _ = reference_run(device, 40000, 50, 0.5, 3, 0.002, 0, model=model)
-    runs = [slab_run(device, X0, 3, 50, 0.002, 6, "hip", 2, model=model, tail_tiles=tail)[0] for tail in (0, 16, 9)]
+    runs = [slab_run(device, X0, 3, 50, 0.002, 6, "hip", 2, model=model, tail_tiles=tail)[0] for tail in (0, 16, 9, 1 << 20)]   # the last: every tile of both launches as halves
     assert np.abs(runs[0] - X0).max() > 1e-3
     for X in runs[1:]:
         assert np.array_equal(runs[0].view(np.uint32), X.view(np.uint32))
