@@ -50,6 +50,9 @@ def draw(seed):
     # round 5 (drawn after everything else): grid_force_bits with the last 1 ... 20 tiles of its launches as
     # half tiles in half of the cases (the kernel keeps a list of fewer than four tails whole)
     tail = int(rng.integers(1, 21)) if rng.random() < 0.5 else 0
+    # ... and (drawn after that) a third of the cases each: that draw, the engine's own choice (-1: at these sizes
+    # every tile as halves), every tile as halves by the knob
+    tail = [tail, -1, 1 << 20][int(rng.integers(0, 3))]
     return dict(model=model, n=n, gs=max(gs, 8), cs=cs, dist=dist, seed=int(seed), dt=dt, steps=steps,
                 variant=variant, lanes=lanes if variant == 3 else 0, stage_v=stage_v, tail=tail)
 
