@@ -2950,7 +2950,11 @@ protected:
                 constexpr int NC = ya::N_floats<Pt>::value + 4;
                 YA_CHECK(ya_device_synchronize());
                 if (d_tail_exchange[part]) ya_free(d_tail_exchange[part]), ya_free(d_tail_tickets[part]);
-                const size_t slots = (size_t)std::max(room, 768) + 8;
+                // once per solver, not once per size: a system that grows (proliferation) asks for a tile more
+                // every few steps while its launches are made of halves, which they are up to `resident` tiles
+                const int most = std::min((grid.n_max + ya::bits::BLOCK - 1) / ya::bits::BLOCK,
+                    std::max(resident_workgroups<ya::grid_force_bits<Pt, pw_int, pw_friction, false, false>>(), 768));
+                const size_t slots = (size_t)std::max(room, most) + 8;
                 YA_CHECK(ya_malloc((void**)&d_tail_exchange[part], slots * 2 * NC * ya::bits::BLOCK * sizeof(float)));
                 YA_CHECK(ya_malloc((void**)&d_tail_tickets[part], slots * sizeof(int)));
                 YA_CHECK(ya_memset_async(d_tail_tickets[part], 0, slots * sizeof(int), nullptr));
