@@ -107,6 +107,7 @@ void distances(const int n1, const int n2, const Pt1* d_X1, const Pt2* d_X2, flo
     if (n2 > 0)
         squared<<<dim3(blocks, (n2 + slice - 1) / slice), BLOCK>>>(n1, n2, d_X1, d_X2, slice, bits);
     roots<<<(n1 + 255) / 256, 256>>>(n1, d_min_dist);
+    YA_CHECK((int)hipGetLastError());
 }
 
 // Sum of d_v[0 .. n) in ONE fixed order (lane t of a single 1024-lane workgroup adds elements t, t + 1024, ...
@@ -130,6 +131,7 @@ inline float sum(const float* d_v, const int n)
     float* d_sum;
     YA_CHECK(ya_malloc((void**)&d_sum, sizeof(float)));
     total<<<1, 1024>>>(n, d_v, d_sum);
+    YA_CHECK((int)hipGetLastError());
     float out;
     YA_CHECK(ya_memcpy_d2h(&out, d_sum, sizeof(float)));
     ya_free(d_sum);
