@@ -146,9 +146,19 @@ def parse(argv=None):
     ap.add_argument("--slab", action="store_true",
                     help="use the z-slab path (ghost exchange + all-reduce) even on 1 GPU")
     ap.add_argument("--tail-tiles", type=int, default=-1,
-                    help="grid_force_bits: the last this-many tiles of a launch as two half-tile workgroups each "
-                         "(-1 = the engine's choice: 768 for launches of 6144 tiles or more, 0 = none); an A/B knob, "
-                         "results do not depend on it")
+                    help="grid_force_bits under --sum-order 1: the last this-many tiles of a launch as two half-tile "
+                         "workgroups each (-1 = the engine's choice: 768 for launches of 6144 tiles or more, 0 = none); "
+                         "an A/B knob, results do not depend on it")
+    ap.add_argument("--sum-order", type=int, default=0, choices=[0, 1],
+                    help="Grid_computer::sum_order: 0 = the reference's one running sum per cell (default, "
+                         "bit-comparable with the oracle's default), 1 = own z-plane | other planes (opt-in; the only "
+                         "order in which --tail-tiles / half-tile workgroups exist)")
+    ap.add_argument("--preheat-ms", type=float, default=400.0,
+                    help="before the warm-up steps: this many milliseconds of dt = 0 steps on a SCRATCH copy of the "
+                         "system (never on the system that is timed), so that the timed region does not start on an "
+                         "idle GPU's clock ramp; 0 = none.  Reported as preheat_ms")
+    ap.add_argument("--no-tail-ab-line", action="store_true",
+                    help="headline run: skip the extra untimed pass with --sum-order 1 (reported as tail_ab)")
     ap.add_argument("--force-variant", type=int, default=-1,
                     help="-1 = the engine's choice (default: grid_force_bits, or grid_force_coop below ~1.5e5 cells "
                          "when the model declared its functors stateless), 2 = grid_force_bits always, "
@@ -493,10 +503,11 @@ def main(argv=None):
     n_links = 0
     link_pairs = None
 
-    def make_sim(lib=None):
+    def make_sim(lib=None, sum_order=None):
         """The undivided system of this run, ready for its first step (called again for the untimed
         passes that repeat the timed steps: force-kernel events, the fast tier)."""
         nonlocal n_links, link_pairs
+        sum_order = args.sum_order if sum_order is None else sum_order
         if state is not None:
             sim = cases.from_state(state, lib or engine)
         else:
@@ -504,6 +515,8 @@ def main(argv=None):
             sim.random_sphere(args.dist, 42)
         if "grid" in args.model:
             sim.set_param("force_variant", args.force_variant)
+            if sum_order:
+                sim.set_param("sum_order", sum_order)
             if args.tail_tiles != -1:
                 sim.set_param("tail_tiles", args.tail_tiles)
             sim.set_param("sorted_pipeline", args.sorted_pipeline)
@@ -558,6 +571,8 @@ def main(argv=None):
         del X0
         sim = my_slab.sim
         sim.set_param("force_variant", args.force_variant)
+        if args.sum_order:
+            sim.set_param("sum_order", args.sum_order)
         if args.tail_tiles != -1:
             sim.set_param("tail_tiles", args.tail_tiles)
         if args.model == "sorting_grid":
@@ -578,6 +593,30 @@ def main(argv=None):
                 step_no[0] += 1
                 slab_step(step_no[0] % args.migrate_every == 0)
 
+    def preheat(make_scratch):
+        """dt = 0 steps on a SCRATCH system for --preheat-ms, so that what follows does not start on the clock
+        ramp of an idle GPU (the device sat idle while the host generated the system).  Returns the scratch
+        system (closed by the caller AFTER its pass: freeing syncs the device) and what was done."""
+        if args.preheat_ms <= 0 or args.sustained:
+            return None, {"ms": 0.0, "steps": 0}
+        scratch = make_scratch()
+        scratch.take_step(0.0, 2)   # (allocations, first launches)
+        scratch.synchronize()
+        t = time.perf_counter()
+        steps = 0
+        while (time.perf_counter() - t) * 1e3 < args.preheat_ms:
+            scratch.take_step(0.0, 25)
+            steps += 25
+            scratch.synchronize()
+        return scratch, {"ms": (time.perf_counter() - t) * 1e3, "steps": steps}
+
+    def slab_scratch():
+        n_s = max(n_total // world, 1000)
+        scratch = Solution("springs_grid", n_s, grid_size_for(n_s, args.dist), 1.0)
+        scratch.random_sphere(args.dist, 42)
+        return scratch
+
+    scratch, preheat_facts = preheat(slab_scratch if slab_path else make_sim)
     advance(args.warmup)
     barrier()
     # The engine replays small systems' steps as a hipGraph (Heun_solver::graph_steps), which
@@ -588,9 +627,10 @@ def main(argv=None):
     sampler = None
     stop_sampling = None
 
-    def start_clock_sampler():
-        """The shader clock beside a run: a wavefront of its own on a stream of its own, every 50 ms
-        (ya_shader_clock_mhz probes the device that is current for the calling thread)."""
+    def start_clock_sampler(every_s=0.05):
+        """The shader clock beside a run: a wavefront of its own on a stream of its own, every 50 ms (2 ms beside
+        the headline's 12 ms events pass; ya_shader_clock_mhz probes the device that is current for the calling
+        thread)."""
         import ctypes as C
         import threading
         core = C.CDLL(_ffi.CORE_LIB, mode=C.RTLD_LOCAL)
@@ -603,19 +643,19 @@ def main(argv=None):
             mhz = C.c_double()
             while not stop.is_set():
                 if core.ya_shader_clock_mhz(200.0, C.byref(mhz)) == 0:
-                    samples.append(mhz.value)
-                stop.wait(0.05)
+                    samples.append((time.perf_counter(), mhz.value))
+                stop.wait(every_s)
 
         thread = threading.Thread(target=sample_clock, daemon=True)
         thread.start()
         return thread, stop, samples
 
     def clock_summary(samples):
-        cs = sorted(samples)
+        cs = sorted(s[1] if isinstance(s, tuple) else s for s in samples)
         return {"samples": len(cs), "min": cs[0] if cs else None, "median": cs[len(cs) // 2] if cs else None,
                 "max": cs[-1] if cs else None,
                 "how": "ya_shader_clock_mhz: s_memtime against the 100 MHz wall clock, one wavefront beside the run, "
-                       "every 50 ms"}
+                       "every 50 ms (2 ms beside the headline's events pass)"}
 
     if args.sustained and rank == 0:
         sampler, stop_sampling, clock_samples = start_clock_sampler()
@@ -633,22 +673,63 @@ def main(argv=None):
     # the launches that were timed; events on every launch cost ~24 us of stream time per step, which
     # is why they are not inside the timed region any more).  On the z-slab path and in graph mode it
     # continues from the state the timed region left.
-    if not slab_path and not graph_mode and not args.sustained:
+    if scratch is not None:
+        scratch.close()
+    headline_clock = None
+
+    def events_pass_on_fresh_copy(sum_order=None):
+        """The timed region repeated on a fresh copy of the system -- same seed, same preheat, same warm-up, the
+        same K steps -- with events on every force launch and the shader clock sampled beside it.  Events and
+        sampler are switched on BEFORE the preheat (their first use allocates: events, a stream, pinned memory), so
+        that nothing but the K steps happens between the warm-up and the end of the pass; only what falls into the
+        K steps is reported."""
+        nonlocal sim
         sim.close()
-        sim = make_sim()
+        sim = make_sim(sum_order=sum_order)
+        thread, stop, samples = start_clock_sampler(0.002)
+        sim.profile(True, every=1)
+        scratch, _ = preheat(lambda: make_sim(sum_order=sum_order))
         advance(args.warmup)
         barrier()
-        sim.profile(True, every=1)
+        sim.profile_read()   # (the warm-up's launches: dropped)
+        t1 = time.perf_counter()
         advance(args.steps)
         barrier()
+        t2 = time.perf_counter()
+        stop.set()
+        thread.join()
+        ms, count = sim.profile_read()
+        sim.profile(False)
+        if scratch is not None:
+            scratch.close()
+        return ms, count, t2 - t1, clock_summary([mhz for t, mhz in samples if t1 <= t <= t2])
+
+    tail_ab = None
+    if not slab_path and not graph_mode and not args.sustained:
+        force_ms, launches, events_seconds, headline_clock = events_pass_on_fresh_copy()
         events_pass = "the timed steps repeated on a fresh copy of the system, events on every force launch"
+        if (rank == 0 and world == 1 and args.model in STATELESS_MODELS and "grid" in args.model and args.sum_order == 0
+                and args.force_variant in (-1, 2) and state is None and not args.no_tail_ab_line):
+            # A/B the driver can see: the same pass with Grid_computer::sum_order = YA_SUM_BY_PLANE, i.e. with the
+            # tail of half-tile workgroups the engine then chooses (round 5's default; opt-in since round 6)
+            ab_ms, ab_launches, ab_seconds, _ = events_pass_on_fresh_copy(sum_order=1)
+            tail_ab = {
+                "force_us_reference_order_whole_tiles": force_ms / max(launches, 1) * 1e3,
+                "force_us_by_plane_half_tile_tail": ab_ms / max(ab_launches, 1) * 1e3,
+                "ms_per_step_reference_order": events_seconds / args.steps * 1e3,
+                "ms_per_step_by_plane": ab_seconds / args.steps * 1e3,
+                "tail_tiles": args.tail_tiles,
+                "what": "the timed steps repeated twice on fresh copies with events on every force launch: "
+                        "--sum-order 0 (the default: the reference's one running sum per cell, whole tiles) and "
+                        "--sum-order 1 (own plane | other planes, the last tiles of a launch as half-tile workgroups: "
+                        "768 of 15625 at 10^6 cells); the ms_per_step figures include ~24 us of event overhead per step"}
     else:
         sim.profile(True, every=1 if graph_mode else args.time_every)
         advance(min(args.steps, 10 if graph_mode or slab_path else 20))
         barrier()
         events_pass = "steps after the timed region, from the state it left"
-    force_ms, launches = sim.profile_read()
-    sim.profile(False)
+        force_ms, launches = sim.profile_read()
+        sim.profile(False)
     if not slab_path:
         assert sim.get_d_n() == n_total
         n_force = n_total
@@ -701,6 +782,9 @@ def main(argv=None):
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
+            # before the W warm-up steps: dt = 0 steps on a scratch copy (never the timed system), see --preheat-ms
+            "preheat_ms": preheat_facts["ms"],
+            "preheat_steps_on_scratch_copy": preheat_facts["steps"],
             # N > 1: one 10 M-cell system over N GPUs (total work fixed).  N = 1 is the 1 M-cell
             # headline and NOT the base of that curve: see one_gpu_same_system on the N > 1 lines.
             "scaling": "strong",
@@ -724,6 +808,7 @@ def main(argv=None):
                 "cube_size": 1.0,
                 "step_replayed_as_hipgraph": bool(graph_mode),
                 "force_variant": args.force_variant,
+                "sum_order": "reference (one running sum per cell)" if args.sum_order == 0 else "by plane (opt-in)",
                 "arith": args.arith,
                 "links": n_links if not slab_path else 0,
                 "renumber_every": args.renumber_every,
@@ -781,6 +866,10 @@ def main(argv=None):
                 "what": "dt = %g: every take_step does all its work on the same state (no drift of the workload)" % dt,
                 "shader_clock_mhz": clock_summary(clock_samples),
             }
+        if headline_clock is not None:
+            out["headline_clock_mhz"] = headline_clock   # sampled beside the events pass (a repeat of the timed steps)
+        if tail_ab is not None:
+            out["tail_ab"] = tail_ab
         if rccl_facts is not None:
             out["rccl"] = rccl_facts
         if world > 1:

@@ -646,7 +646,7 @@ inline float cutoff_squared(float cube_size)
 
 }  // namespace ya
 #ifdef YA_EXPERIMENTAL_FORCE_VARIANTS
-#include "experimental/force_variants.cuh"  // grid_force_direct, grid_force (byte FIFO): A/B baselines for tests and tools
+#include "force_variants.cuh"  // tools/ab/: grid_force_direct, grid_force (byte FIFO) -- A/B baselines for tests and tools (-Itools/ab)
 #endif
 namespace ya {
 
@@ -675,7 +675,7 @@ namespace ya {
 // CUs, and the workgroup needs 7 KiB of LDS.  MI355X, same box (tools/micro/force_ab.hip):
 // 242 us per 1 M-cell launch against 260 us for round 1's byte-FIFO kernel, 62 against 75 us at 10^5 cells,
 // 803 against 853 us at 4 M.  What bounds it is the VALU issue rate.
-// Results are bit-identical to the earlier kernels' (include/experimental/force_variants.cuh): same candidates, same
+// Results are bit-identical to the earlier kernels' (tools/ab/force_variants.cuh): same candidates, same
 // order, same arithmetic.
 // The friction terms of one pair (solvers.cuh:309-313, :453-458): sum_friction += friction,
 // sum_v += friction * old_v[j].  For the default functor friction_w_neighbour the coefficient
@@ -705,7 +705,7 @@ __device__ __forceinline__ void pair_friction(const Pt& Xi, const Pt& r, const f
 }
 
 // Hooks of tools/micro/force_trace.hip (when and where every workgroup of a launch ran): empty
-// unless include/experimental/force_trace.cuh was included first.
+// unless tools/ab/force_trace.cuh was included first.
 #ifndef YA_BITS_PROBE_BEGIN
 #define YA_BITS_PROBE_BEGIN
 #define YA_BITS_PROBE_END(tile_)
@@ -888,7 +888,7 @@ __global__ __launch_bounds__(bits::BLOCK, bits::Min_waves<Pt>::value) void grid_
     const int* __restrict__ cube_id, const int* __restrict__ offs, const int gs,
     const int n_cubes, const float cut2, Pt* __restrict__ d_dX, const bool has_gen,
     const int n_active, Pt* __restrict__ d_dX_sorted, const int* __restrict__ global_id, const int n_tiles,
-    const int tail, float* tail_exchange, int* tail_tickets,
+    const int tail, float* tail_exchange, int* tail_tickets, const bool by_plane,
     const int part = 0, const int part_cube_lo = 0, const int part_cube_hi = 0, const int own_cube_lo = 0,
     const int own_cube_hi = 0x7fffffff)
 {
@@ -918,8 +918,12 @@ __global__ __launch_bounds__(bits::BLOCK, bits::Min_waves<Pt>::value) void grid_
     // mirrored cells costs nothing), and with two ranges the XCDs in the middle of the list got
     // nearly twice the work of those at its ends -- all of them also carry an eighth of part 2.
     //
-    // Round 5, THE TAIL: a launch ends with one wavefront lifetime at falling occupancy (16 % of a launch of
-    // 10^6 cells).  The last `tail` tiles of a launch's list are therefore given to TWO one-wavefront
+    // SUMMATION ORDER.  by_plane = false (Grid_computer::sum_order = YA_SUM_REFERENCE, the default): every
+    // cell's terms go to ONE running sum over the nine rows in the reference's d_nhood order -- the
+    // reference's arithmetic (solvers.cuh:437-459) -- and every tile is a whole tile (tail == 0).
+    // by_plane = true (YA_SUM_BY_PLANE, a model's opt-in): S[dz = 0] + S[dz = -1, +1], which is what lets
+    // THE TAIL exist (round 5): a launch ends with one wavefront lifetime at falling occupancy (16 % of a launch of
+    // 10^6 cells).  The last `tail` tiles of a launch's list are then given to TWO one-wavefront
     // workgroups each -- half 0 the cells' own z-plane (~63 % of the pairs), half 1 the planes below and above
     // -- that live half as long and meet through memory: the half that finishes first leaves its sums in the
     // exchange area and draws the tile's ticket, the half that draws the second ticket adds the other's sums
@@ -1002,7 +1006,7 @@ __global__ __launch_bounds__(bits::BLOCK, bits::Min_waves<Pt>::value) void grid_
     const int plane_first = half == 1 ? 1 : 0, plane_end = half == 0 ? 1 : 3;
 #pragma unroll 1
     for (int plane = plane_first; plane < plane_end; plane++) {
-        if (half < 0 && plane == 1) {
+        if (by_plane && half < 0 && plane == 1) {
             float save[NC];
 #pragma unroll
             for (int k = 0; k < NF; k++) save[k] = field(F, k);
@@ -1073,10 +1077,17 @@ __global__ __launch_bounds__(bits::BLOCK, bits::Min_waves<Pt>::value) void grid_
     for (int k = 0; k < NF; k++) sums[k] = field(F, k);
     sums[NF] = sum_v.x, sums[NF + 1] = sum_v.y, sums[NF + 2] = sum_v.z, sums[NF + 3] = sum_friction;
     if (half < 0) {
+        if (by_plane) {
 #pragma unroll
-        for (int k = 0; k < NC; k++)  // S[dz = 0] + S[dz = -1, +1]
-            sums[k] = (OWN_IN_LDS ? sh_own[k * FB + threadIdx.x] : own[OWN_IN_LDS ? 0 : k]) + sums[k];
+            for (int k = 0; k < NC; k++)  // S[dz = 0] + S[dz = -1, +1]
+                sums[k] = (OWN_IN_LDS ? sh_own[k * FB + threadIdx.x] : own[OWN_IN_LDS ? 0 : k]) + sums[k];
+        }
     } else {
+        // INVARIANT the hand-over below relies on (not promised by the HIP memory model; guarded by
+        // tests/test_parity_gpu.py::test_tail_exchange_over_many_launches): both halves of a tile run on ONE
+        // XCD (blocks whole + 16 g + x and whole + 16 g + 8 + x: same x = blockIdx % 8), the sums are
+        // stored with device-scope (sc1) relaxed atomics that go past that XCD's L2, and the ticket is drawn
+        // only after `s_waitcnt vmcnt(0)` has seen every one of those stores acknowledged.
         // Device-scope relaxed atomic stores and loads (sc1) are performed past the XCD's L2, so no fence is
         // needed for the DATA (a device-scope release fence would write back the whole L2 once per workgroup:
         // 65 us per 1024 workgroups, core.hip's one-launch reduction).  What orders the sums before the ticket
@@ -1113,11 +1124,6 @@ __global__ __launch_bounds__(bits::BLOCK, bits::Min_waves<Pt>::value) void grid_
     YA_BITS_PROBE_END(tile)
 }
 
-}  // namespace ya
-#ifdef YA_EXPERIMENTAL_FORCE_HALVES
-#include "experimental/force_halves.cuh"  // round-5 experiments, both rejected (force_variant 6 / 7: tools/micro/force_ab.hip only)
-#endif
-namespace ya {
 
 // ---------------------------------------------------------------------------------
 // grid_force_coop (the solver's own choice below ~7 * 10^4 cells for functors declared YA_STATELESS;
@@ -1137,8 +1143,8 @@ namespace ya {
 //      friction) and leaves the pair's terms {F, friction, friction * old_v} in LDS;
 //   C  ONE lane per component adds the round's terms to that component's sum in list order.
 //
-// Every per-cell sum is therefore accumulated in exactly the order of the kernels above (own plane | other
-// planes, each in the reference's order) and the result is bit-identical to theirs.  What changes is the same as for tile_force_coop: the
+// Every per-cell sum is therefore accumulated in exactly the order of the kernels above (the reference's one
+// running sum, or own plane | other planes under YA_SUM_BY_PLANE) and the result is bit-identical to theirs.  What changes is the same as for tile_force_coop: the
 // functor is called for one i from several lanes at once, so functors that update per-cell
 // state non-atomically (d_mes_nbs[i] += 1, examples/passive_growth.cu:48-51) must keep one
 // lane per cell.  A, B and C of a cell run inside one wavefront: the only workgroup barriers
@@ -1164,7 +1170,12 @@ struct Stage {
 // grid_force_bits with EVERY tile as two half-tile workgroups while all of them are resident at once
 // (Grid_computer::forces): 53 us at 10^5 cells where 4 lanes take 58 (their 1250 workgroups no longer fit
 // the chip in one round from 8 * 10^4 cells on), 63 at 1.5 * 10^5 where they take 79 and whole tiles 71.
-inline int lanes_for(const int n) { return n <= 15000 ? 16 : (n <= 40000 ? 8 : (n <= 70000 ? 4 : 1)); }
+// Under the default summation order (no half tiles) four lanes per cell stay ahead of whole tiles up to
+// ~1.2 * 10^5 cells (10^5: 58 against 62 us; 1.5 * 10^5: 79 against 71).
+inline int lanes_for(const int n, const bool by_plane = false)
+{
+    return n <= 15000 ? 16 : (n <= 40000 ? 8 : (n <= (by_plane ? 70000 : 120000) ? 4 : 1));
+}
 // LDS traffic between the lanes of ONE wavefront: the hardware keeps a wavefront's LDS
 // operations in order, the compiler must too.
 __device__ __forceinline__ void wave_sync()
@@ -1180,7 +1191,7 @@ __global__ __launch_bounds__(coop::BLOCK) void grid_force_coop(const int n,
     const Entry<Pt>* __restrict__ sorted, const float4* __restrict__ sorted_v,
     const int* __restrict__ cube_id, const int* __restrict__ offs, const int gs,
     const int n_cubes, const float cut2, Pt* __restrict__ d_dX, const bool has_gen,
-    const int n_active, Pt* __restrict__ d_dX_sorted, const int* __restrict__ global_id)
+    const int n_active, Pt* __restrict__ d_dX_sorted, const int* __restrict__ global_id, const bool by_plane)
 {
     static_assert(LANES == 4 || LANES == 8 || LANES == 16, "lanes per cell");
     constexpr int CELLS = coop::BLOCK / LANES, MAX_HITS = coop::MAX_HITS;
@@ -1244,13 +1255,15 @@ __global__ __launch_bounds__(coop::BLOCK) void grid_force_coop(const int n,
     __syncthreads();
 
     float acc[SLOTS];  // this lane's component sums (components lane, lane + LANES, ...)
-    // The engine's summation order (grid_force_bits, "the tail"): the own plane's sums (rows 0-2) are kept
-    // aside and the other planes' summed from +0; the two are added at the end.  A cell's hit list never
-    // mixes the two: listing stops before row 3 until the own plane's list has been worked off.
+    // by_plane (Grid_computer::sum_order = YA_SUM_BY_PLANE; grid_force_bits, "the tail"): the own plane's sums
+    // (rows 0-2) are kept aside and the other planes' summed from +0; the two are added at the end.  A cell's
+    // hit list never mixes the two: listing stops before row 3 until the own plane's list has been worked off.
+    // Otherwise (the default, the reference's order) one running sum: own_done from the start, acc_own stays +0
+    // (and +0 + x is x for every x a sum that started at +0 can hold: never -0).
     float acc_own[SLOTS];
 #pragma unroll
     for (int a = 0; a < SLOTS; a++) acc[a] = 0.f, acc_own[a] = 0.f;
-    bool own_done = false;
+    bool own_done = !by_plane;
 #define YA_COOP_OWN_DONE                                          \
     {                                                             \
         _Pragma("unroll") for (int a = 0; a < SLOTS; a++) acc_own[a] = acc[a], acc[a] = 0.f; \
@@ -1261,7 +1274,7 @@ __global__ __launch_bounds__(coop::BLOCK) void grid_force_coop(const int n,
 #pragma unroll 1
     for (int g0 = 0; g0 < 9; g0 += rows_at_once) {
         const int g_end = g0 + rows_at_once;
-        if (g0 == 3) YA_COOP_OWN_DONE  // plane by plane: every list is worked off at the end of a chunk
+        if (g0 == 3 && !own_done) YA_COOP_OWN_DONE  // plane by plane: every list is worked off at the end of a chunk
         const int g_base = g0 == 0 ? 0 : (g0 == 3 ? v0[3] : v0[6]);
         const int g_total = (g_end == 9 ? v0[9] : (g_end == 3 ? v0[3] : v0[6])) - g_base;
 #pragma unroll 1
@@ -2709,19 +2722,29 @@ private:
 
 __constant__ int d_nhood[27];  // stencil offsets for model kernels (solvers.cuh:428)
 
+enum Ya_sum_order { YA_SUM_REFERENCE = 0, YA_SUM_BY_PLANE = 1 };  // Grid_computer::sum_order
+
 template<typename Pt>
 class Grid_computer {
 public:
     float cube_size;
     ya::Profiler profiler;
     // 2 = grid_force_bits (bit stream) always; 1 = grid_force (byte FIFO), 0 = grid_force_direct: the A/B
-    // baselines of include/experimental/force_variants.cuh, only with -DYA_EXPERIMENTAL_FORCE_VARIANTS;
+    // baselines of tools/ab/force_variants.cuh, only with -DYA_EXPERIMENTAL_FORCE_VARIANTS;
     // 3 = grid_force_coop below ~7 * 10^4 cells (16, 8 or 4 lanes per cell, more the smaller the
     // system), grid_force_bits above: for models whose functors keep no per-cell state without
     // atomics (bit-identical results; see the kernel's comment)
     // -1 (default) = grid_force_bits, or -- for functors declared stateless (YA_STATELESS) --
     // grid_force_coop below ~7 * 10^4 cells
     int force_variant = -1;
+    // The order in which a cell's pair terms are added (both restated in oracle/yalla_host.hpp under the same names):
+    //   YA_SUM_REFERENCE (default)  one running sum over the 27 cubes in d_nhood order -- the reference's
+    //                               thread (solvers.cuh:437-459), bit for bit for + - * / sqrt fma functors;
+    //   YA_SUM_BY_PLANE  (opt-in)   S[own z-plane] + S[planes below and above], each in the reference's order:
+    //                               lets grid_force_bits give a tile's planes to two wavefronts ("the tail";
+    //                               launches of 7 * 10^4 .. 1.6 * 10^5 cells as halves altogether).  ~1e-7
+    //                               relative per step beside the reference's sum, inside north_star's 1e-5.
+    Ya_sum_order sum_order = YA_SUM_REFERENCE;
     int coop_lanes = 0;            // force_variant 3: 0 = from n (ya::coop::lanes_for), or 4 / 8 / 16
     int stage_v_max = 130000;      // grid_force_bits keeps old_v in LDS too up to this many cells
     Grid_computer(int n_max, int grid_size = 50, float cube_size = 1)
@@ -2777,16 +2800,6 @@ public:
         }();
         return resident;
     }
-#ifdef YA_EXPERIMENTAL_FORCE_HALVES
-    float* d_halves_exchange = nullptr;  // (force_variant 6 / 7, tools/micro/force_ab.hip: never freed before exit)
-    int* d_halves_tickets = nullptr;
-    int halves_tiles = 0;
-    long persistent_launches = 0;
-#ifndef YA_MIXED_TAIL_DEFAULT
-#define YA_MIXED_TAIL_DEFAULT 0
-#endif
-    int persistent_blocks = 0, persistent_tail_turns = 0, mixed_tail_tiles = YA_MIXED_TAIL_DEFAULT;
-#endif
     bool sorted_pipeline = true;  // false = both stages through d_X / d_X1 (A/B)
     // z-slab decomposition (include/slab_logic.inc): 1 = the next forces() call launches the tiles
     // in the z-planes next to the slab's faces only (cube ids below force_part_cube_lo or from
@@ -2859,6 +2872,7 @@ protected:
         hipEvent_t start, stop;
         profiler.next(&start, &stop);
         const float cut2 = ya::cutoff_squared(cube_size);
+        const bool by_plane = sum_order == YA_SUM_BY_PLANE;
         // a timed launch carries its events in the dispatch itself (ya::Profiler); an untimed
         // one is a plain launch, which is also what a stream capture records
 #define YA_FORCE_LAUNCH(kernel_, grid_, block_, ...)                                          \
@@ -2870,7 +2884,11 @@ protected:
         // the kernel this launch goes to: an explicit choice, or by what the model said about its functors
         const int force_variant = this->force_variant >= 0 ? this->force_variant
                                   : (ya::stateless_pair<Pt, pw_int, pw_friction>() ? 3 : 2);
-        const int lanes = force_variant == 3 ? (coop_lanes ? coop_lanes : ya::coop::lanes_for(n)) : 1;
+        const int lanes = force_variant == 3 ? (coop_lanes ? coop_lanes : ya::coop::lanes_for(n, by_plane)) : 1;
+        if (force_variant < 0 || force_variant > 3) {
+            fprintf(stderr, "yalla-hip: Grid_computer::force_variant %d is not a kernel (-1, 0, 1, 2, 3)\n", force_variant);
+            abort();
+        }
         // two launches per stage (force_part) are what grid_force_bits offers; the other kernels
         // compute every tile in the first call
         const bool bits_kernel = lanes == 1 && force_variant >= 2;
@@ -2908,20 +2926,20 @@ protected:
     YA_FORCE_LAUNCH((ya::grid_force_coop<Pt, pw_int, pw_friction, lanes_>),                    \
         (n + ya::coop::BLOCK / lanes_ - 1) / (ya::coop::BLOCK / lanes_), ya::coop::BLOCK, n,   \
         d_cells, d_cells_v, (const int*)grid.d_cube_id, grid.offsets(), grid.grid_size,        \
-        grid.n_cubes, cut2, d_dX, has_gen, n_active, d_dX_in_cell_order, (const int*)d_global_id)
+        grid.n_cubes, cut2, d_dX, has_gen, n_active, d_dX_in_cell_order, (const int*)d_global_id, by_plane)
         if (lanes == 16) {
             YA_COOP_LAUNCH(16);
         } else if (lanes == 8) {
             YA_COOP_LAUNCH(8);
         } else if (lanes == 4) {
             YA_COOP_LAUNCH(4);
-        } else if (force_variant >= 2 && force_variant < 6) {
+        } else if (force_variant == 2 || force_variant == 3) {
 #define YA_BITS_LAUNCH(stage_v_, gids_)                                                        \
     YA_FORCE_LAUNCH((ya::grid_force_bits<Pt, pw_int, pw_friction, stage_v_, gids_>),           \
         tail < 0 ? 16 * ((tiles + 7) / 8) : tiles + (tail > 0 ? std::min(tail, tiles) + 24 : 0), ya::bits::BLOCK, n, d_cells, \
         d_cells_v, (const int*)grid.d_cube_id, grid.offsets(), grid.grid_size, grid.n_cubes, cut2, d_dX,  \
         has_gen, n_active, d_dX_in_cell_order, (const int*)d_global_id, tiles, tail,           \
-        d_tail_exchange[part], d_tail_tickets[part], part, force_part_cube_lo,                 \
+        d_tail_exchange[part], d_tail_tickets[part], by_plane, part, force_part_cube_lo,                 \
         force_part_cube_hi, force_own_cube_lo, force_own_cube_hi)
             const int tiles = (n + ya::bits::BLOCK - 1) / ya::bits::BLOCK;
             // Half tiles (grid_force_bits, "the tail"; > 0: the last so many tiles of the launch, < 0: all).
@@ -2932,7 +2950,7 @@ protected:
             // at once: only for functors declared stateless (YA_STATELESS; relu_w_epithelium's
             // `d_mes_nbs[i] += 1` would lose counts).
             int tail = 0;
-            if (ya::stateless_pair<Pt, pw_int, pw_friction>()) {
+            if (by_plane && ya::stateless_pair<Pt, pw_int, pw_friction>()) {
                 if (force_tail_tiles >= 0) {
                     tail = force_tail_tiles >= tiles ? -1 : force_tail_tiles;
                 } else {
@@ -2976,74 +2994,20 @@ protected:
             }
 #undef YA_BITS_LAUNCH
         }
-#ifdef YA_EXPERIMENTAL_FORCE_HALVES
-        else if (force_variant == 6) {
-            const int tiles = (n + ya::bits::BLOCK - 1) / ya::bits::BLOCK;
-            constexpr int NC = ya::N_floats<Pt>::value + 4;
-            if (halves_tiles < tiles) {
-                if (d_halves_exchange) ya_free(d_halves_exchange), ya_free(d_halves_tickets);
-                halves_tiles = (grid.n_max + ya::bits::BLOCK - 1) / ya::bits::BLOCK;
-                YA_CHECK(ya_malloc((void**)&d_halves_exchange, (size_t)halves_tiles * 2 * NC * ya::bits::BLOCK * sizeof(float)));
-                YA_CHECK(ya_malloc((void**)&d_halves_tickets, (size_t)halves_tiles * sizeof(int)));
-                YA_CHECK(ya_memset_async(d_halves_tickets, 0, (size_t)halves_tiles * sizeof(int), nullptr));
-                YA_CHECK(ya_device_synchronize());
-            }
-            YA_FORCE_LAUNCH((ya::grid_force_halves<Pt, pw_int, pw_friction>), 16 * ((tiles + 7) / 8), ya::bits::BLOCK, n,
-                d_cells, d_cells_v, (const int*)grid.d_cube_id, grid.offsets(), grid.grid_size, grid.n_cubes, cut2, d_dX,
-                has_gen, n_active, d_dX_in_cell_order, d_halves_exchange, d_halves_tickets, tiles);
-        }
-        else if (force_variant == 8) {
-            const int tiles = (n + ya::bits::BLOCK - 1) / ya::bits::BLOCK;
-            constexpr int NC = ya::N_floats<Pt>::value + 4;
-            if (halves_tiles < tiles) {
-                if (d_halves_exchange) ya_free(d_halves_exchange), ya_free(d_halves_tickets);
-                halves_tiles = (grid.n_max + ya::bits::BLOCK - 1) / ya::bits::BLOCK;
-                YA_CHECK(ya_malloc((void**)&d_halves_exchange, (size_t)halves_tiles * 2 * NC * ya::bits::BLOCK * sizeof(float)));
-                YA_CHECK(ya_malloc((void**)&d_halves_tickets, (size_t)halves_tiles * sizeof(int)));
-                YA_CHECK(ya_memset_async(d_halves_tickets, 0, (size_t)halves_tiles * sizeof(int), nullptr));
-                YA_CHECK(ya_device_synchronize());
-            }
-            // the last `mixed_tail_tiles` tiles in dispatch order as halves
-            const int whole = tiles > mixed_tail_tiles ? (tiles - mixed_tail_tiles) & ~7 : 0;
-            YA_FORCE_LAUNCH((ya::grid_force_mixed<Pt, pw_int, pw_friction>), whole + 16 * ((tiles - whole + 7) / 8),
-                ya::bits::BLOCK, n, d_cells, d_cells_v, (const int*)grid.d_cube_id, grid.offsets(), grid.grid_size,
-                grid.n_cubes, cut2, d_dX, has_gen, n_active, d_dX_in_cell_order, d_halves_exchange, d_halves_tickets, tiles,
-                whole);
-        }
-        else if (force_variant == 7) {
-            const int tiles = (n + ya::bits::BLOCK - 1) / ya::bits::BLOCK;
-            constexpr int NC = ya::N_floats<Pt>::value + 4;
-            if (halves_tiles < tiles) {
-                if (d_halves_exchange) ya_free(d_halves_exchange), ya_free(d_halves_tickets);
-                halves_tiles = (grid.n_max + ya::bits::BLOCK - 1) / ya::bits::BLOCK;
-                YA_CHECK(ya_malloc((void**)&d_halves_exchange, (size_t)halves_tiles * 2 * NC * ya::bits::BLOCK * sizeof(float)));
-                YA_CHECK(ya_malloc((void**)&d_halves_tickets, ((size_t)halves_tiles + 512) * sizeof(int)));
-                YA_CHECK(ya_memset_async(d_halves_tickets, 0, ((size_t)halves_tiles + 512) * sizeof(int), nullptr));
-                YA_CHECK(ya_device_synchronize());
-            }
-            int* queues = d_halves_tickets + halves_tiles;  // two sets of 8 (a cache line each), used alternately
-            const int set = (int)(persistent_launches++ & 1);
-            const int resident = persistent_blocks > 0 ? persistent_blocks : 5120;
-            YA_FORCE_LAUNCH((ya::grid_force_persistent<Pt, pw_int, pw_friction>), resident < tiles ? resident : tiles,
-                ya::bits::BLOCK, n, d_cells, d_cells_v, (const int*)grid.d_cube_id, grid.offsets(), grid.grid_size, grid.n_cubes,
-                cut2, d_dX, has_gen, n_active, d_dX_in_cell_order, d_halves_exchange, d_halves_tickets, queues + 256 * set,
-                queues + 256 * (1 - set), tiles, persistent_tail_turns);
-        }
-#endif
 #ifdef YA_EXPERIMENTAL_FORCE_VARIANTS
         else if (force_variant == 0) {
             YA_FORCE_LAUNCH((ya::grid_force_direct<Pt, pw_int, pw_friction>), blocks, ya::FORCE_BLOCK, n,
                 d_cells, d_cells_v, (const int*)grid.d_cube_id, grid.offsets(), grid.grid_size,
-                grid.n_cubes, cube_size, d_dX, has_gen, n_active, (const int*)d_global_id);
+                grid.n_cubes, cube_size, d_dX, has_gen, n_active, (const int*)d_global_id, by_plane);
         } else {
             YA_FORCE_LAUNCH((ya::grid_force<Pt, pw_int, pw_friction>), blocks, ya::FORCE_BLOCK, n, d_cells,
                 d_cells_v, (const int*)grid.d_cube_id, grid.offsets(), grid.grid_size, grid.n_cubes,
-                cut2, d_dX, has_gen, n_active, d_dX_in_cell_order, (const int*)d_global_id);
+                cut2, d_dX, has_gen, n_active, d_dX_in_cell_order, (const int*)d_global_id, by_plane);
         }
 #else
         else {
             fprintf(stderr, "yalla-hip: Grid_computer::force_variant %d is an A/B baseline kept in "
-                            "include/experimental/force_variants.cuh: compile with -DYA_EXPERIMENTAL_FORCE_VARIANTS\n", force_variant);
+                            "tools/ab/force_variants.cuh: compile with -DYA_EXPERIMENTAL_FORCE_VARIANTS -Itools/ab\n", force_variant);
             abort();
         }
 #endif

@@ -28,10 +28,12 @@
 // x*x))), division of a Pt by a scalar = multiplication by float(1.0/b)
 // (dtypes.cuh:202-208).
 //
-// ONE deliberate difference in association from the reference (round 5): Grid_computer::pwints sums a cell's
-// terms as S[own z-plane] + S[planes below and above], each partial sum in the reference's stencil order --
-// the engine's documented order, ~1e-7 relative per step beside the reference's single
-// sum.  (The centre-of-mass sum has two documented orders as well: set_reduce_order.)
+// Summation orders.  The DEFAULTS are the reference's: Grid_computer::pwints adds the terms of all 27 cubes to
+// ONE running sum per cell (solvers.cuh:437-459; Grid_computer::sum_order = YA_SUM_REFERENCE), and the
+// centre-of-mass sum runs left to right (reduce_order = YA_REDUCE_SERIAL).  Each has a second, documented
+// order that restates what the HIP engine does when asked to: YA_SUM_BY_PLANE (the engine's opt-in order
+// for half-tile workgroups: S[own z-plane] + S[planes below and above]) and YA_REDUCE_TREE (the engine's
+// fixed tree).  The engine's DEFAULT grid sum is the reference's single sum as well.
 #pragma once
 
 #include <assert.h>
@@ -449,11 +451,23 @@ inline Pair_trace& pair_trace()
     return t;
 }
 
+// The order in which Grid_computer::pwints adds a cell's pair terms:
+//   YA_SUM_REFERENCE  one running sum over the 27 cubes in d_nhood order, cells of a cube in ascending
+//                     slot order -- the reference's thread (solvers.cuh:437-459).  THE DEFAULT.
+//   YA_SUM_BY_PLANE   the terms of the cell's own z-plane (stencil entries 0-8) and those of the planes
+//                     below and above (9-26) summed separately, each in the reference's order from +0, and
+//                     the two sums added: what the HIP engine computes when a model opts into
+//                     Grid_computer::sum_order = YA_SUM_BY_PLANE so that a tile's planes may go to two
+//                     wavefronts (include/solvers.cuh, "the tail").  ~1e-7 relative per step beside the
+//                     reference's sum (tests/test_sum_order_gpu.py measures it).
+enum Ya_sum_order { YA_SUM_REFERENCE = 0, YA_SUM_BY_PLANE = 1 };
+
 // Grid_computer: solvers.cuh:430-502
 template<typename Pt>
 class Grid_computer {
 public:
     float cube_size;
+    Ya_sum_order sum_order = YA_SUM_REFERENCE;
     Grid_computer(int n_max, int grid_size = 50, float cube_size = 1)
         : cube_size{cube_size}, grid{n_max, grid_size}
     {
@@ -503,16 +517,14 @@ protected:
             memset(&F, 0, sizeof(Pt));
             float3 sum_v{0, 0, 0};
             float sum_friction = 0;
-            // THE ENGINE'S SUMMATION ORDER (not the reference's, whose thread adds all 27 cubes' terms to one
-            // sum, :437-459): the terms of the cell's own z-plane (stencil entries 0-8) and those of the planes
-            // below and above (9-26) are summed separately, each in the reference's order from +0, and the two
-            // sums added -- so that the device may give a tile's planes to two wavefronts.
+            // YA_SUM_BY_PLANE only (not the reference): the own plane's sums are set aside when the walk
+            // reaches stencil entry 9, and added to the other planes' at the end.
             Pt F_own;
             memset(&F_own, 0, sizeof(Pt));
             float3 sum_v_own{0, 0, 0};
             float sum_friction_own = 0;
             for (int j = 0; j < 27; j++) {
-                if (j == 9) {
+                if (j == 9 && sum_order == YA_SUM_BY_PLANE) {
                     F_own = F, sum_v_own = sum_v, sum_friction_own = sum_friction;
                     memset(&F, 0, sizeof(Pt));
                     sum_v = float3{0, 0, 0};
@@ -537,9 +549,14 @@ protected:
                     sum_v += friction * d_old_v[pk];
                 }
             }
-            d_dX[pi] += F_own + F;
-            d_sum_v[pi] = sum_v_own + sum_v;
-            d_sum_friction[pi] = sum_friction_own + sum_friction;
+            if (sum_order == YA_SUM_BY_PLANE) {
+                F = F_own + F;
+                sum_v = sum_v_own + sum_v;
+                sum_friction = sum_friction_own + sum_friction;
+            }
+            d_dX[pi] += F;              // :460
+            d_sum_v[pi] = sum_v;        // :461
+            d_sum_friction[pi] = sum_friction;  // :462
         }
     }
 };

@@ -53,14 +53,20 @@ def draw(seed):
     # ... and (drawn after that) a third of the cases each: that draw, the engine's own choice (-1: at these sizes
     # every tile as halves), every tile as halves by the knob
     tail = [tail, -1, 1 << 20][int(rng.integers(0, 3))]
+    # round 6 (drawn last): the summation order of the grid force, in BOTH libraries -- the reference's one
+    # running sum (Grid_computer::sum_order 0, the default) in two thirds of the cases, by plane (1: the only
+    # order in which the drawn tail of half tiles exists) in the others
+    sum_order = int(rng.random() < 0.34)
     return dict(model=model, n=n, gs=max(gs, 8), cs=cs, dist=dist, seed=int(seed), dt=dt, steps=steps,
-                variant=variant, lanes=lanes if variant == 3 else 0, stage_v=stage_v, tail=tail)
+                variant=variant, lanes=lanes if variant == 3 else 0, stage_v=stage_v, tail=tail, sum_order=sum_order)
 
 
 def run_case(oracle, device, c):
     out = []
     for lib in (oracle, device):
         with Solution(c["model"], c["n"], c["gs"], c["cs"], lib=lib) as s:
+            if c["model"].endswith("_grid"):
+                assert s.set_param("sum_order", c.get("sum_order", 0)) == 0
             if lib is oracle:
                 assert s.set_reduce_order(1) == 0
             elif c["model"].endswith("_grid"):

@@ -6,6 +6,18 @@ and cannot run in this image (CUDA), so these fixtures pin the *oracle* (and
 through it the HIP engine) against regressions: inputs are regenerated from the
 seed by random_sphere (glibc rand(), deterministic), expected outputs are the
 oracle's.  Run from the repo root:  python tests/golden/make_golden.py
+
+What is stored per case:
+  X, old_v          the oracle with the REFERENCE's grid summation order (one running sum per cell,
+                    ref solvers.cuh:437-459; Grid_computer::sum_order = YA_SUM_REFERENCE, the default of the
+                    oracle AND of the HIP engine) and the engine's centre-of-mass tree (YA_REDUCE_TREE)
+  X_serial_reduce   the same with the serial centre-of-mass sum: the oracle's all-defaults reading of the reference
+  X_by_plane        grid cases: the engine's OPT-IN own-plane | other-planes order (YA_SUM_BY_PLANE), tree COM
+
+clipped_grid_n4096_100steps pins nothing physical: springs + friction_w_neighbour are chaotic over 100 steps (the
+tree and the serial COM order alone move every cell by ~1.4, 148 % of the system's extent; so do the two grid
+summation orders).  It is a BIT-REGRESSION fixture only -- same order, same bits -- which is why the cross-order
+comparisons in tests/test_golden.py skip runs of more than 10 steps.
 """
 import os
 import sys
@@ -35,11 +47,13 @@ CASES = {
 }
 
 
-def run(lib, case, tree):
+def run(lib, case, tree, sum_order=0):
     model, n, gs, cs, dist, seed, dt, steps, extras = CASES[case]
     with Solution(model, n, gs, cs, lib=lib) as s:
         if lib.ya_models_is_device() == 0:
             s.set_reduce_order(1 if tree else 0)
+        if sum_order:
+            s.set_param("sum_order", sum_order)
         if "links" in extras:
             s.h_X[:] = [(1, 1, 0), (1, -1, 0), (-1, -1, 0), (-1, 1, 0)]
             s.copy_to_device()
@@ -68,6 +82,8 @@ def main():
         tree = run(lib, case, True)
         serial = run(lib, case, False)
         tree["X_serial_reduce"] = serial["X"]
+        if "grid" in CASES[case][0]:
+            tree["X_by_plane"] = run(lib, case, True, sum_order=1)["X"]
         np.savez_compressed(os.path.join(OUT, case + ".npz"), **tree)
         print(case, {k: v.shape for k, v in tree.items()})
 

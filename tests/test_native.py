@@ -134,7 +134,7 @@ def test_force_launch_trace(tmp_path):
     assert s["block_mod_8_is_the_xcd"]
     assert 1 <= s["resident_workgroups_per_cu_max"] <= 24
     assert s["mean_lifetime"] > 0 and sum(s["in_flight"]) > 0
-    # the engine's choice at this size: as many tiles split in two as fill the chip's 5120 wavefront slots in
+    # the engine's choice at this size under the opt-in by-plane summation order: as many tiles split in two as fill the chip's 5120 wavefront slots in
     # the launch's one round -- every workgroup still stamped once, the halves of a tile on one XCD
     split = traced()
     assert 5100 <= split["workgroups"] <= 5128 and split["block_mod_8_is_the_xcd"]

@@ -17,12 +17,16 @@ pytestmark = pytest.mark.gpu
 REL_TOL = 1e-5  # BASELINE.json north_star: "within 1e-5 relative on fp32 positions"
 
 
-def run_both(oracle, device, model, n, gs, cs, dist, seed, dt, steps, tree=True, setup=None):
+def run_both(oracle, device, model, n, gs, cs, dist, seed, dt, steps, tree=True, setup=None, sum_order=0):
+    """sum_order: 0 = the reference's one running sum per cell (the default of both libraries), 1 = the
+    engine's opt-in own-plane | other-planes order (Grid_computer::sum_order), selected in BOTH."""
     out = []
     for lib in (oracle, device):
         with Solution(model, n, gs, cs, lib=lib) as s:
             if lib is oracle and tree:
                 assert s.set_reduce_order(1) == 0
+            if sum_order:
+                assert s.set_param("sum_order", sum_order) == 0
             s.random_sphere(dist, seed)
             if setup:
                 setup(s)
@@ -70,14 +74,18 @@ def test_other_functors_bit_exact(oracle, device, model):
 
 
 # (force_variant, coop_lanes, stage_v_max[, tail_tiles]): grid_force_direct, grid_force, grid_force_bits with
-# old_v from global memory and from LDS, grid_force_coop with 16, 8 and 4 lanes per cell, and
-# grid_force_bits with the last 40 / 8 tiles (or all tiles) of every launch as half tiles that meet through memory
-FORCE_KERNELS = [(0, 0, 0), (1, 0, 0), (2, 0, 0), (2, 0, 1 << 30), (3, 16, 0), (3, 8, 0), (3, 4, 0),
-                 (2, 0, 0, 40), (2, 0, 1 << 30, 8), (2, 0, 0, 1 << 20)]   # the last: EVERY tile as halves
+# old_v from global memory and from LDS, grid_force_coop with 16, 8 and 4 lanes per cell; and, only under
+# sum_order 1 (own plane | other planes), grid_force_bits with the last 40 / 8 tiles (or all tiles) of every launch
+# as half tiles that meet through memory
+FORCE_KERNELS = [(0, 0, 0), (1, 0, 0), (2, 0, 0), (2, 0, 1 << 30), (3, 16, 0), (3, 8, 0), (3, 4, 0)]
+HALF_TILE_KERNELS = [(2, 0, 0, 40), (2, 0, 1 << 30, 8), (2, 0, 0, 1 << 20)]   # the last: EVERY tile as halves
+# (kernel, sum_order): every kernel in the reference's order, every kernel and the half tiles by plane
+KERNELS_AND_ORDERS = [(k, 0) for k in FORCE_KERNELS] + [(k, 1) for k in FORCE_KERNELS + HALF_TILE_KERNELS]
 
 
-def select_kernel(s, kernel):
+def select_kernel(s, kernel, sum_order=0):
     variant, lanes, stage_v_max = kernel[:3]
+    assert s.set_param("sum_order", sum_order) == 0
     s.set_param("force_variant", variant)
     s.set_param("coop_lanes", lanes)
     s.set_param("stage_v_max", stage_v_max)
@@ -88,29 +96,35 @@ def test_all_force_kernels_agree(oracle, device):
     """grid_force_bits (bit-stream hit list, the default; old_v from global memory or LDS),
     grid_force (byte FIFO), grid_force_direct (the reference's structure) and grid_force_coop
     (several lanes per cell) are the same sums in the same order: bit-identical to each other
-    and to the oracle."""
+    and to the oracle -- in the reference's summation order (the default) and, with half tiles too,
+    in the opt-in by-plane order, each against the oracle's restatement of that order."""
     n = 30000
-    res = []
-    for kernel in FORCE_KERNELS:
+    res = {0: [], 1: []}
+    for kernel, order in KERNELS_AND_ORDERS:
         (Xo, vo, _), (Xd, vd, _) = run_both(
-            oracle, device, "springs_grid", n, 50, 1.0, 0.5, 4, 0.001, 2,
-            setup=lambda s: select_kernel(s, kernel) if s.lib is device else None)
-        assert np.array_equal(Xo.view(np.uint32), Xd.view(np.uint32)), kernel
-        assert np.array_equal(vo.view(np.uint32), vd.view(np.uint32)), kernel
-        res.append(Xd)
-    for X in res[1:]:
-        assert np.array_equal(res[0].view(np.uint32), X.view(np.uint32))
+            oracle, device, "springs_grid", n, 50, 1.0, 0.5, 4, 0.001, 2, sum_order=order,
+            setup=lambda s: select_kernel(s, kernel, order) if s.lib is device else None)
+        assert np.array_equal(Xo.view(np.uint32), Xd.view(np.uint32)), (kernel, order)
+        assert np.array_equal(vo.view(np.uint32), vd.view(np.uint32)), (kernel, order)
+        res[order].append(Xd)
+    for order in (0, 1):
+        for X in res[order][1:]:
+            assert np.array_equal(res[order][0].view(np.uint32), X.view(np.uint32))
+    # the two orders are different roundings of the same sums: not the same bits, far inside 1e-5
+    assert not np.array_equal(res[0][0].view(np.uint32), res[1][0].view(np.uint32))
+    assert_close_positions(res[0][0], res[1][0])
 
 
 def test_tail_of_half_tiles_at_its_default_size(oracle, device):
-    """450 000 cells are 7032 tiles: the launch ends with 768 tiles as pairs of half-tile workgroups
-    (Grid_computer::forces).  The oracle's bits, and the bits of a launch of whole tiles only."""
+    """450 000 cells are 7032 tiles: with sum_order 1 the launch ends with 768 tiles as pairs of half-tile
+    workgroups (Grid_computer::forces).  The by-plane oracle's bits, and the bits of a launch of whole tiles only."""
     n = 450000
-    (Xo, vo, _), (Xd, vd, _) = run_both(oracle, device, "springs_grid", n, 64, 1.0, 0.5, 11, 0.001, 1)
+    (Xo, vo, _), (Xd, vd, _) = run_both(oracle, device, "springs_grid", n, 64, 1.0, 0.5, 11, 0.001, 1, sum_order=1)
     assert np.array_equal(Xo.view(np.uint32), Xd.view(np.uint32))
     assert np.array_equal(vo.view(np.uint32), vd.view(np.uint32))
     with Solution("springs_grid", n, 64, 1.0, lib=device) as s:
         s.random_sphere(0.5, 11)
+        assert s.set_param("sum_order", 1) == 0
         s.set_param("tail_tiles", 0)
         s.take_step(0.001, 1)
         assert np.array_equal(s.positions().view(np.uint32), Xd.view(np.uint32))
@@ -125,6 +139,7 @@ def test_tail_exchange_over_many_launches(device):
     for tail in (-1, 0):
         with Solution("springs_grid", n, 64, 1.0, lib=device) as s:
             s.random_sphere(0.5, 5)
+            assert s.set_param("sum_order", 1) == 0
             s.set_param("tail_tiles", tail)
             s.take_step(0.001, 300)
             out.append(s.positions())
@@ -134,14 +149,16 @@ def test_tail_exchange_over_many_launches(device):
 
 def test_cooperative_kernel_picks_its_lanes_from_n(oracle, device):
     """force_variant 3 with the lanes per cell left to ya::coop::lanes_for: 16, 8 and 4 lanes and, above
-    7 * 10^4 cells, the one-lane kernel -- made of half tiles altogether while they are all resident at once
-    (10^5, 1.6 * 10^5 cells), of whole tiles beyond (2 * 10^5) -- always the oracle's bits."""
-    for n, gs in ((9000, 40), (30000, 50), (60000, 50), (100000, 64), (160000, 64), (200000, 64)):
-        (Xo, vo, _), (Xd, vd, _) = run_both(
-            oracle, device, "springs_grid", n, gs, 1.0, 0.5, 4, 0.001, 1,
-            setup=lambda s: s.set_param("force_variant", 3) if s.lib is device else None)
-        assert np.array_equal(Xo.view(np.uint32), Xd.view(np.uint32)), n
-        assert np.array_equal(vo.view(np.uint32), vd.view(np.uint32)), n
+    1.2 * 10^5 cells (7 * 10^4 under sum_order 1), the one-lane kernel -- under sum_order 1 made of half tiles
+    altogether while they are all resident at once (10^5, 1.6 * 10^5 cells), of whole tiles beyond (2 * 10^5)
+    -- always the bits of the oracle in the same order."""
+    for order in (0, 1):
+        for n, gs in ((9000, 40), (30000, 50), (60000, 50), (100000, 64), (160000, 64), (200000, 64)):
+            (Xo, vo, _), (Xd, vd, _) = run_both(
+                oracle, device, "springs_grid", n, gs, 1.0, 0.5, 4, 0.001, 1, sum_order=order,
+                setup=lambda s: s.set_param("force_variant", 3) if s.lib is device else None)
+            assert np.array_equal(Xo.view(np.uint32), Xd.view(np.uint32)), (n, order)
+            assert np.array_equal(vo.view(np.uint32), vd.view(np.uint32)), (n, order)
 
 
 @pytest.mark.parametrize("model,n,dist,cube", [
@@ -153,16 +170,17 @@ def test_cooperative_kernel_picks_its_lanes_from_n(oracle, device):
 def test_force_kernels_agree_on_dense_rows(device, model, n, dist, cube):
     """The kernels against each other where a lane's row exceeds one pass of the bit stream,
     the plane exceeds the staging capacity and a cell's hits exceed its list: bit-identical."""
-    res = []
-    for kernel in FORCE_KERNELS:
+    res = {0: [], 1: []}
+    for kernel, order in KERNELS_AND_ORDERS:
         with Solution(model, n, 50, cube, lib=device) as s:
             s.random_sphere(dist, 5)
-            select_kernel(s, kernel)
+            select_kernel(s, kernel, order)
             s.take_step(0.0005, 2)
-            res.append((s.positions(), s.old_v()))
-    for X, v in res[1:]:
-        assert np.array_equal(res[0][0].view(np.uint32), X.view(np.uint32))
-        assert np.array_equal(res[0][1].view(np.uint32), v.view(np.uint32))
+            res[order].append((s.positions(), s.old_v()))
+    for order in (0, 1):
+        for X, v in res[order][1:]:
+            assert np.array_equal(res[order][0][0].view(np.uint32), X.view(np.uint32))
+            assert np.array_equal(res[order][0][1].view(np.uint32), v.view(np.uint32))
 
 
 def test_both_second_stage_pipelines_agree(oracle, device):

@@ -37,8 +37,9 @@ def slab_run(lib, X0, world, gs, dt, steps, device="cpu", migrate_every=1, model
     if force_variant is not None:
         for s in slabs:
             s.sim.set_param("force_variant", force_variant)
-    if tail_tiles is not None:
+    if tail_tiles is not None:   # half tiles exist under the by-plane summation order only
         for s in slabs:
+            assert s.sim.set_param("sum_order", 1) == 0
             s.sim.set_param("tail_tiles", tail_tiles)
     if model.startswith("sorting"):
         for s in slabs:

@@ -1,0 +1,134 @@
+"""The HIP engine against the oracle's ALL-DEFAULTS reading of the reference -- ONE running sum per cell over
+the 27 cubes (ref include/solvers.cuh:437-459, oracle YA_SUM_REFERENCE) and the left-to-right centre-of-mass
+sum (ref :242,268, oracle YA_REDUCE_SERIAL) -- for the functor of every BASELINE.json configuration, at
+>= 20 000 cells, over >= 10 steps in lock-step (every step starts from the oracle's state: the dynamics
+amplify rounding, tests/test_fast_arith_gpu.py).
+
+Two engine settings are measured against that one oracle:
+  default      Grid_computer::sum_order = YA_SUM_REFERENCE: the reference's association.  What differs from the
+               oracle is the centre-of-mass tree alone (and libm's last ulp in sorting / bending functors); with
+               the oracle's tree order the libm-free cases are bit-identical (test_parity_gpu.py).
+  by plane     the opt-in YA_SUM_BY_PLANE (half-tile workgroups): own z-plane | other planes.
+Both must stay within north_star's 1e-5 relative on positions; the worst ratios are written to
+profiles/r06_sum_order_gap.json (gpurun_out/ on the GPU box) so the deviation is measured, not assumed."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from yalla_amd import cases
+from yalla_amd.solution import Solution
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-5   # BASELINE.json north_star
+STEPS = 10
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LOG = {}
+
+
+def restart(sd, so, n):
+    sd.h_X[:] = so.h_X
+    sd.h_n = n
+    sd.copy_to_device()
+    sd.set_old_v(so.old_v())
+
+
+def lock_step(name, make, dt, cut_off_pairs=0, props=()):
+    """make(lib) -> a Solution in the start state.  Returns the worst per-step relative deviation of the two
+    engine settings from the oracle's all-defaults run."""
+    so = make("oracle")
+    so.set_reduce_order(0)                       # serial centre-of-mass sum: the plain reading of :242
+    assert so.set_param("sum_order", 0) == 0     # ... and the reference's one running sum (the default)
+    sd = {"default": make("device"), "by_plane": make("device")}
+    assert sd["by_plane"].set_param("sum_order", 1) == 0
+    worst = {k: 0.0 for k in sd}
+    flips = {k: 0 for k in sd}
+    n = so.get_d_n()
+    for step in range(STEPS):
+        so.take_step(dt)
+        Xo = so.positions()
+        scale = np.abs(Xo[:, :3]).max()
+        for k, s in sd.items():
+            s.take_step(dt)
+            assert s.get_d_n() == n
+            diff = np.abs(Xo[:, :3] - s.positions()[:, :3]).max(axis=1)
+            # a pair within rounding of the cut-off may interact in one run and not in the other where the
+            # force does not vanish there (spring: ~0.5 dt per cell): counted, bounded, not part of the ratio
+            off = int((diff > REL_TOL * scale).sum())
+            assert off <= cut_off_pairs, (name, k, step, off, float(diff.max()))
+            flips[k] += off
+            worst[k] = max(worst[k], float(np.sort(diff)[-1 - off] / scale))
+            for p in props:
+                assert np.array_equal(so.get_prop(p, n), s.get_prop(p, n)), (name, k, p, step)
+            restart(s, so, n)
+    for s in sd.values():
+        s.close()
+    so.close()
+    LOG[name] = {"cells": int(n), "steps": STEPS, "dt": dt,
+                 "worst_rel_default_order_vs_reference": worst["default"],
+                 "worst_rel_by_plane_order_vs_reference": worst["by_plane"],
+                 "cells_moved_by_a_cut_off_flip": flips}
+    for k in worst:
+        assert worst[k] <= REL_TOL, (name, k, worst[k])
+    return worst
+
+
+@pytest.fixture(scope="module")
+def libs(oracle, device):
+    return {"oracle": oracle, "device": device}
+
+
+def sphere(libs, model, n, gs, dist, seed, setup=None):
+    def make(which):
+        s = Solution(model, n, gs, 1.0, lib=libs[which])
+        s.random_sphere(dist, seed)
+        if setup:
+            setup(s)
+        return s
+    return make
+
+
+def test_config5_springs(libs):
+    """Headline functor (examples/springs.cu:14-21 cut off by the grid), random_sphere(0.5)."""
+    n = 50_000
+    lock_step("springs_grid", sphere(libs, "springs_grid", n, 64, 0.5, 42), 0.001, cut_off_pairs=4)
+
+
+def test_config2_sorting(libs):
+    """examples/sorting.cu: differential_adhesion (powf), two cell types."""
+    n = 20_000
+    lock_step("sorting_grid", sphere(libs, "sorting_grid", n, 50, 0.5, 42, lambda s: s.set_param("n_cells", n)), 0.05)
+
+
+@pytest.mark.parametrize("model", ["clipped_grid", "relu_grid", "relu_po_grid", "relu_cell_grid"])
+def test_clipped_and_relu_on_every_point_type(libs, model):
+    """clipped_spring (tests/test_solvers.cu:44-53) and relu_force (inits.cuh:78-93) on float3, Po_cell, Cell."""
+    lock_step(model, sphere(libs, model, 20_000, 64, 0.6, 5), 0.1)
+
+
+def test_config3_branching_functor(libs):
+    """epi_turing_mes_noturing (examples/branching.cu:60-110) on a 20 000-cell relaxed sphere with its
+    epithelium, division frozen; the neighbour counters (integer atomics) must be identical."""
+    state = cases.config3_state(libs["device"], 20_000)
+    lock_step("branching_grid", lambda which: cases.from_state(state, libs[which]), 0.2, props=("mes_nbs", "epi_nbs"))
+
+
+def test_config4_passive_growth_functor(libs):
+    """relu_w_epithelium (examples/passive_growth.cu:30-57) on a system grown to >= 20 000 cells, division frozen."""
+    state = cases.config4_state(libs["device"], target=20_000, rate=0.05)
+    lock_step("passive_growth_grid", lambda which: cases.from_state(state, libs[which]), 0.2, props=("mes_nbs",))
+
+
+def test_zz_log_written():
+    """(runs last in this module) the measured gaps, for profiles/r06_sum_order_gap.json"""
+    assert len(LOG) >= 8
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    doc = {"what": "HIP engine vs the oracle's all-defaults reading of the reference (one running sum per cell, "
+                   "ref solvers.cuh:437-459; serial centre-of-mass sum, ref :242,268), lock-step, worst |dX| / max|X| "
+                   "over the steps; tolerance 1e-5 (north_star)",
+           "tolerance": REL_TOL, "cases": LOG}
+    with open(os.path.join(out, "r06_sum_order_gap.json"), "w") as f:
+        json.dump(doc, f, indent=1)

@@ -13,7 +13,7 @@
 // (round 4: they were in solvers.cuh itself, instantiated for every functor of every model).
 #pragma once
 #ifndef YA_EXPERIMENTAL_FORCE_VARIANTS
-#error "include/experimental/force_variants.cuh is pulled in by solvers.cuh under -DYA_EXPERIMENTAL_FORCE_VARIANTS"
+#error "tools/ab/force_variants.cuh is pulled in by solvers.cuh under -DYA_EXPERIMENTAL_FORCE_VARIANTS"
 #endif
 
 namespace ya {
@@ -25,7 +25,7 @@ __global__ __launch_bounds__(FORCE_BLOCK) void grid_force_direct(const int n,
     const Entry<Pt>* __restrict__ sorted, const float4* __restrict__ sorted_v,
     const int* __restrict__ cube_id, const int* __restrict__ offs, const int gs,
     const int n_cubes, const float cube_size, Pt* __restrict__ d_dX, const bool has_gen,
-    const int n_active, const int* __restrict__ global_id)
+    const int n_active, const int* __restrict__ global_id, const bool by_plane)
 {
     const int s = blockIdx.x * FORCE_BLOCK + threadIdx.x;
     if (s >= n) return;
@@ -40,13 +40,14 @@ __global__ __launch_bounds__(FORCE_BLOCK) void grid_force_direct(const int n,
     Pt F = ya::zero<Pt>();
     float3 sum_v{0.f, 0.f, 0.f};
     float sum_friction = 0;
-    // the engine's summation order (grid_force_bits): the own plane's sums (rows 0-2) kept aside, the
-    // other planes' summed from +0, the two added at the end
+    // by_plane (Grid_computer::sum_order = YA_SUM_BY_PLANE): the own plane's sums (rows 0-2) kept aside, the
+    // other planes' summed from +0, the two added at the end.  Otherwise the reference's one running sum:
+    // the _own sums stay +0, and +0 + x == x for every x a sum that started at +0 can hold (never -0).
     Pt F_own = ya::zero<Pt>();
     float3 sum_v_own{0.f, 0.f, 0.f};
     float sum_friction_own = 0;
     for (int row = 0; row < 9; row++) {
-        if (row == 3) {
+        if (row == 3 && by_plane) {
             F_own = F, sum_v_own = sum_v, sum_friction_own = sum_friction;
             F = ya::zero<Pt>(), sum_v = float3{0.f, 0.f, 0.f}, sum_friction = 0;
         }
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(FORCE_BLOCK) void grid_force(const int n,
     const Entry<Pt>* __restrict__ sorted, const float4* __restrict__ sorted_v,
     const int* __restrict__ cube_id, const int* __restrict__ offs, const int gs,
     const int n_cubes, const float cut2, Pt* __restrict__ d_dX, const bool has_gen,
-    const int n_active, Pt* __restrict__ d_dX_sorted, const int* __restrict__ global_id)
+    const int n_active, Pt* __restrict__ d_dX_sorted, const int* __restrict__ global_id, const bool by_plane)
 {
     constexpr int CAP = Stage_cells<Pt>::value;
     __shared__ __attribute__((aligned(16))) Entry<Pt> sh_e[CAP + 8];  // slack: phase 1 reads whole groups
@@ -171,12 +172,12 @@ __global__ __launch_bounds__(FORCE_BLOCK) void grid_force(const int n,
     int slot0 = 0, slot1 = 0, slot2 = 0;        // the same anchors as slots of the sorted arrays
 
     int next_lo[3], next_hi[3], next_begin[3], next_end[3];
-    Pt F_own = ya::zero<Pt>();  // the engine's summation order: own plane | other planes (grid_force_bits)
+    Pt F_own = ya::zero<Pt>();  // by_plane only: own plane | other planes (grid_force_bits); else they stay +0
     float3 sum_v_own{0.f, 0.f, 0.f};
     float sum_friction_own = 0;
     YA_ROW_BOUNDS(0)
     for (int plane = 0; plane < 3; plane++) {
-        if (plane == 1) {  // (the FIFOs are empty at the end of every plane)
+        if (plane == 1 && by_plane) {  // (the FIFOs are empty at the end of every plane)
             F_own = F, sum_v_own = sum_v, sum_friction_own = sum_friction;
             F = ya::zero<Pt>(), sum_v = float3{0.f, 0.f, 0.f}, sum_friction = 0;
         }

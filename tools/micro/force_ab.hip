@@ -3,7 +3,8 @@
 // Builds the grid once on a state that `warm` take_steps have relaxed, then times
 // variant 1 (grid_force, byte FIFO) and variant 2 (grid_force_bits, compiled with this
 // executable's -DYA_BITS_BLOCK / -DYA_BITS_POPS / -DYA_MASK_WORDS flags) in interleaved rounds with HIP events,
-// (AB_BASE / AB_TEST select other pairs: 3 = grid_force_coop, 12 = grid_force_bits with old_v in LDS)
+// (AB_BASE / AB_TEST select other pairs: 3 = grid_force_coop, 12 = grid_force_bits with old_v in LDS,
+// 102 = grid_force_bits summing by plane, with the tail of half tiles)
 // and compares their outputs (d_dX by id and d_dX in sorted order) bit for bit.
 // One JSON line per run; tools/micro/force_ab.sh builds and runs a set of configurations.
 #include <algorithm>
@@ -36,20 +37,16 @@ struct Probe : public Solution<Pt, Grid_solver> {
     void build(int n) { this->grid.build_sorted(n, this->d_X, this->d_old_v, this->cube_size, this->d_sorted, this->d_sorted_v); }
     void run(int n, int variant, Pt* out, Pt* out_sorted)
     {
-        // variants >= 10: variant - 10 with old_v staged in LDS whatever n is; < 10: never staged
+        // variant % 100 >= 10: old_v staged in LDS whatever n is; < 10: never staged
         this->force_variant = variant % 10;
 #ifdef YA_COOP_LANES
         this->coop_lanes = YA_COOP_LANES;  // variant 3: fixed instead of chosen from n
 #endif
-        this->stage_v_max = variant >= 10 ? 2000000000 : 0;
-#if defined(AB_TAIL_TURNS) && defined(YA_EXPERIMENTAL_FORCE_HALVES)
-        this->persistent_tail_turns = AB_TAIL_TURNS;  // variant 7: an XCD's last this-many tiles as halves
-#endif
-#if defined(AB_MIXED_TAIL) && defined(YA_EXPERIMENTAL_FORCE_HALVES)
-        this->mixed_tail_tiles = AB_MIXED_TAIL;  // variant 8: the last this-many tiles of a launch as halves
-#endif
-#if defined(AB_PERSISTENT_BLOCKS) && defined(YA_EXPERIMENTAL_FORCE_HALVES)
-        this->persistent_blocks = AB_PERSISTENT_BLOCKS;
+        this->stage_v_max = variant % 100 >= 10 ? 2000000000 : 0;
+        // variants >= 100: Grid_computer::sum_order = YA_SUM_BY_PLANE (half tiles where the engine chooses them)
+        this->sum_order = variant >= 100 ? YA_SUM_BY_PLANE : YA_SUM_REFERENCE;
+#ifdef AB_TAIL_TILES
+        this->force_tail_tiles = AB_TAIL_TILES;
 #endif
         this->template forces<models::spring, friction_w_neighbour<Pt>>(
             n, this->d_sorted, this->d_sorted_v, out, false, n, out_sorted);
@@ -127,5 +124,5 @@ int main(int argc, char** argv)
         AB_TAG, AB_BASE, AB_TEST, n, gs, dist, warm, rounds, median(us[0]), *std::min_element(us[0].begin(), us[0].end()),
         median(us[1]), *std::min_element(us[1].begin(), us[1].end()), mismatches, max_abs, max_rel, ya::bits::BLOCK,
         ya::bits::WORDS, YA_BITS_POPS);
-    return mismatches != 0 && AB_TEST < 4 && AB_BASE < 4;  // variants 4, 5 sum by plane
+    return mismatches != 0 && (AB_TEST >= 100) == (AB_BASE >= 100);  // the two summation orders differ by rounding
 }

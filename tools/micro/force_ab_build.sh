@@ -6,7 +6,7 @@ mkdir -p ab_bin
 for spec in "$@"; do
   tag=${spec%%:*}; flags=${spec#*:}
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -DYALLA_NO_THRUST \
-    -I../../include -I../../yalla_amd/csrc $flags -DAB_TAG="\"$tag\"" force_ab.hip -o ab_bin/force_ab_$tag \
+    -I../../include -I../ab -I../../yalla_amd/csrc $flags -DAB_TAG="\"$tag\"" force_ab.hip -o ab_bin/force_ab_$tag \
     -L../../yalla_amd -lyalla_hip -Wl,-rpath,'$ORIGIN/../../../yalla_amd' 2>&1 | grep -E "error|warning: (?!unused)" -A3 &
 done
 wait

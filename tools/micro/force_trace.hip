@@ -1,11 +1,11 @@
-// When and where every workgroup of one grid_force_bits launch ran (include/experimental/force_trace.cuh
+// When and where every workgroup of one grid_force_bits launch ran (tools/ab/force_trace.cuh
 // fills the kernel's probe hooks: s_memtime at entry and exit and the hardware ids):
 //   force_trace [cells] [warm steps] [tail tiles: -1 the engine's choice, 0 whole tiles only] > stamps.csv
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
 
-#include "experimental/force_trace.cuh"  // before solvers.cuh: the probe hooks of grid_force_bits
+#include "force_trace.cuh"  // before solvers.cuh: the probe hooks of grid_force_bits
 
 #include "dtypes.cuh"
 #include "inits.cuh"
@@ -41,6 +41,8 @@ int main(int argc, char** argv)
     (void)hipMalloc(&d_out, (size_t)n * sizeof(Pt));
     (void)hipMalloc(&d_outs, (size_t)n * sizeof(Pt));
     cells.force_tail_tiles = argc > 3 ? atoi(argv[3]) : -1;
+    // half tiles exist under the opt-in summation order only (Grid_computer::sum_order)
+    cells.sum_order = cells.force_tail_tiles != 0 ? YA_SUM_BY_PLANE : YA_SUM_REFERENCE;
     const int blocks = 2 * ((n + 63) / 64) + 64;  // room for a launch of half tiles; blocks that never ran stay zero
     unsigned long long* d_trace;
     (void)hipMalloc(&d_trace, (size_t)blocks * 4 * sizeof(unsigned long long));

@@ -147,6 +147,7 @@ class Solution:
     # --- model extras --------------------------------------------------------
     def set_param(self, name, value):
         _check(self.lib.ya_sim_set_param(self._h, name.encode(), float(value)), "set_param")
+        return 0
 
     def set_prop(self, name, values):
         v = np.ascontiguousarray(values, dtype=np.int32)
