@@ -50,6 +50,7 @@
 #include <string.h>
 
 #include <functional>
+#include <mutex>
 #include <type_traits>
 #include <utility>
 #include <vector>
@@ -2162,6 +2163,7 @@ public:
         const int unused[] = {0, (renumber_one(order, n, arrays, new_id), 0)...};
         (void)unused;
         if (new_id) ya_free(new_id);
+        rhs_zeroed[0] = rhs_zeroed[1] = 0;  // (nothing here writes d_dX / d_dX1; no promise is carried over a renumbering)
         Computer<Pt>::ids_changed();
         // a graph captured NOW would bake the forgotten visit order (n_prev = 0) into its first build:
         // capture again one step later, when the grid remembers an order again
@@ -2229,7 +2231,10 @@ protected:
     ya_n_reader* n_reader = nullptr;
     int sorted_stage_cells = -1;  // stage API: cells in the sorted copy stage 2 may start from
     bool mirrored_in_sorted_copy = false;  // ... and the mirrored cells' predictor is in it already
-    int rhs_zeroed[2] = {0, 0};        // rows of d_dX / d_dX1 an update kernel left zeroed (stage_update_folding)
+    // rows of d_dX / d_dX1 an update kernel left zeroed (stage_update_folding).  INVARIANT: every writer of those two
+    // arrays goes through stage_rhs / sorted_step (which reset the promise) -- the arrays are protected members and
+    // no accessor hands them out; a new path that writes them must reset rhs_zeroed as well.
+    int rhs_zeroed[2] = {0, 0};
     std::function<void()> keep_order;  // keep_in_cube_order: renumber(the registered arrays)
     int keep_order_every = 0, keep_order_wait = 0;
     bool fix_com = true;
@@ -2523,8 +2528,9 @@ protected:
             // the first build reads d_X only and the generic forces write d_dX only, so the build's first
             // three kernels may run before them: the device works while the count travels, instead of
             // standing idle between two steps.)
-            YA_CHECK(ya_n_read_begin(n_reader, d_n, nullptr));
-            Computer<Pt>::begin_build(d_X, d_n, n_max);
+            // (Round 6: the count travels in the first binning kernel itself, ya_grid_build_sorted_begin_publish,
+            // not in a 4-byte copy queued ahead of it: one 4 us kernel fewer in the stream per step.)
+            Computer<Pt>::begin_build(d_X, d_n, n_max, n_reader);
             YA_CHECK(ya_n_read_end(n_reader, &n));
             assert(n <= n_max);
         } else {
@@ -2583,7 +2589,7 @@ protected:
     float step_cube_size() const { return 0; }
     int step_variant() const { return 0; }
     void check_status() {}
-    void begin_build(const Pt*, const int*, int) {}
+    void begin_build(const Pt*, const int*, int, ya_n_reader*) {}
     void cancel_build() {}
     const int* cube_order(int, const Pt*) { return nullptr; }  // no grid: renumber() is a no-op
     void ids_changed() {}
@@ -2667,9 +2673,9 @@ public:
     // build_sorted in two halves: the first one reads the count on the device and can be
     // queued before the host has it (ya_grid_build_sorted_begin / _finish).
     template<typename Pt>
-    void build_sorted_begin(const Pt* d_X, const int* d_n, const int n_bound, const float cube_size)
+    void build_sorted_begin(const Pt* d_X, const int* d_n, const int n_bound, const float cube_size, ya_n_reader* reader)
     {
-        YA_CHECK(ya_grid_build_sorted_begin(handle, d_X, sizeof(Pt), d_n, n_bound, cube_size, nullptr));
+        YA_CHECK(ya_grid_build_sorted_begin_publish(handle, d_X, sizeof(Pt), d_n, n_bound, cube_size, reader, nullptr));
     }
     template<typename Pt>
     void build_sorted_finish(const int n, const Pt* d_X, const float3* d_old_v,
@@ -2703,6 +2709,13 @@ public:
             fprintf(stderr,
                 "yalla-hip: a cell left the cube range its z-slab promised the grid (Grid::set_cube_range): it "
                 "moved more than a cube between two selections of the mirrored cells.\n");
+            abort();
+        }
+        if (bits & YA_STATUS_SCAN_STALLED) {
+            fprintf(stderr,
+                "yalla-hip: the grid build's prefix sum stalled (a workgroup waited for one of lower index that had "
+                "not been started: the device does not dispatch workgroups in index order, or two builds of one "
+                "Grid ran at once on different streams).  The grid arrays of that build are not valid.\n");
             abort();
         }
         if (bits & YA_STATUS_OUT_OF_GRID) {
@@ -2787,18 +2800,23 @@ public:
     float* d_tail_exchange[3] = {nullptr, nullptr, nullptr};  // per launch kind (part 0 / 1 / 2)
     int* d_tail_tickets[3] = {nullptr, nullptr, nullptr};
     int tail_room[3] = {0, 0, 0};
-    // one-wavefront workgroups of `Kernel` the chip holds at once (occupancy x CUs)
+    // one-wavefront workgroups of `Kernel` the CURRENT device holds at once (occupancy x CUs), per device
     template<auto Kernel>
     static int resident_workgroups()
     {
-        static const int resident = [] {
-            int per_cu = 0, device = 0, cus = 0;
+        static std::mutex lock;
+        static std::vector<int> by_device;
+        int device = 0;
+        YA_CHECK((int)hipGetDevice(&device));
+        std::lock_guard<std::mutex> hold(lock);
+        if ((int)by_device.size() <= device) by_device.resize(device + 1, 0);
+        if (by_device[device] == 0) {
+            int per_cu = 0, cus = 0;
             YA_CHECK((int)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, Kernel, ya::bits::BLOCK, 0));
-            YA_CHECK((int)hipGetDevice(&device));
             YA_CHECK((int)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
-            return per_cu * cus;
-        }();
-        return resident;
+            by_device[device] = per_cu * cus;
+        }
+        return by_device[device];
     }
     bool sorted_pipeline = true;  // false = both stages through d_X / d_X1 (A/B)
     // z-slab decomposition (include/slab_logic.inc): 1 = the next forces() call launches the tiles
@@ -3024,9 +3042,9 @@ protected:
     void ids_changed() { grid.forget_order(); }
     // The part of the first stage's grid build that can be queued before the host knows
     // n (Heun_solver::take_step); pwints then only finishes the build.
-    void begin_build(const Pt* d_X, const int* d_n, const int n_bound)
+    void begin_build(const Pt* d_X, const int* d_n, const int n_bound, ya_n_reader* reader)
     {
-        grid.build_sorted_begin(d_X, d_n, n_bound, cube_size);
+        grid.build_sorted_begin(d_X, d_n, n_bound, cube_size, reader);
         build_begun = true;
     }
     void cancel_build() { build_begun = false; }

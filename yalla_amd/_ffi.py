@@ -70,7 +70,7 @@ CORE_ABI = [
     "ya_abi_version", "ya_malloc", "ya_free", "ya_memset_async", "ya_memcpy_h2d",
     "ya_memcpy_d2h", "ya_host_alloc", "ya_host_free", "ya_memcpy_d2d_async", "ya_device_synchronize", "ya_get_n",
     "ya_grid_create", "ya_grid_destroy", "ya_grid_arrays", "ya_grid_offsets",
-    "ya_grid_build", "ya_grid_build_sorted", "ya_grid_build_sorted_begin",
+    "ya_grid_build", "ya_grid_build_sorted", "ya_grid_build_sorted_begin", "ya_grid_build_sorted_begin_publish",
     "ya_grid_build_sorted_finish", "ya_grid_rebuild_sorted", "ya_n_reader_create", "ya_n_reader_destroy",
     "ya_n_read_begin", "ya_n_read_end", "ya_grid_status", "ya_reduce_mean", "ya_reduce_sum_packed",
     "ya_reduce_workspace_bytes", "ya_select_z", "ya_select_workspace_bytes", "ya_gather_rows",

@@ -76,8 +76,15 @@ __global__ __launch_bounds__(BLOCK) void k_bin(const float* __restrict__ X,
     int stride_f, int n, float cs, int gs, int n_cubes, const int* __restrict__ prev_pid,
     int n_prev, int* __restrict__ cube_of, int* __restrict__ rank, int* __restrict__ count,
     int* __restrict__ status, float* __restrict__ stash, int stash_f,
-    const int* __restrict__ d_n, int range_lo, int range_hi)
+    const int* __restrict__ d_n, int range_lo, int range_hi, int* publish = nullptr, int publish_seq = 0)
 {
+    // ya_grid_build_sorted_begin_publish: the count goes to the host from HERE -- {n, sequence number} stored
+    // to host memory the device writes directly (fine-grained, system scope), the count first -- instead of by a
+    // copy queued in front of this kernel (4 us of stream time per step that the build waited for)
+    if (publish && blockIdx.x == 0 && threadIdx.x == 0) {
+        __hip_atomic_store(publish, *d_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(publish + 1, publish_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     if (d_n) n = min(*d_n, n);  // the count still on its way to the host; n = launch bound
     int s = blockIdx.x * BLOCK + threadIdx.x;
     const int n_visit = max(n, n_prev);
@@ -153,7 +160,7 @@ __device__ __forceinline__ int block_sum(int v, int* sh)
 __global__ __launch_bounds__(BLOCK) void k_scan(int* __restrict__ count,
     unsigned long long* __restrict__ tile_state, unsigned* __restrict__ d_epoch, int n_cubes, int n,
     int* __restrict__ offs, int* __restrict__ cube_start, int* __restrict__ cube_end,
-    const int* __restrict__ d_n, int first_tile, int all_tiles)
+    const int* __restrict__ d_n, int first_tile, int all_tiles, int* __restrict__ status)
 {
     if (d_n) n = min(*d_n, n);
     __shared__ int sh[4];
@@ -199,9 +206,19 @@ __global__ __launch_bounds__(BLOCK) void k_scan(int* __restrict__ count,
                        : epoch << 32;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
+            // REQUIREMENT (not promised by HIP, true of every dispatcher this was run on): the blocks of lower
+            // index a block waits for have been STARTED before it.  Should that ever fail (another partition
+            // mode, a runtime that dispatches out of order) the wait gives up after ~0.2 s instead of hanging
+            // every grid build: YA_STATUS_SCAN_STALLED is raised (Grid::check_status aborts with the reason)
+            // and the arrays of this build are wrong, as the message says.
+            int spins = 0;
             while ((v[k] >> 32) != epoch) {  // not published yet
                 __builtin_amdgcn_s_sleep(1);
                 v[k] = __hip_atomic_load(&tile_state[t0 + k * BLOCK], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (++spins > (1 << 22)) {
+                    atomicOr(status, YA_STATUS_SCAN_STALLED);
+                    break;
+                }
             }
             before += (int)(unsigned)v[k];
         }
@@ -880,8 +897,12 @@ int ya_get_n(const int* d_n, int* n_out)
 }
 
 struct ya_n_reader {
-    int* h_n;  // pinned
+    int* h_n;  // pinned, fine-grained: {n, sequence number of the publishing kernel}
+    int* d_view;  // the same two words as the device addresses them
     hipEvent_t done;
+    int seq;        // last sequence number handed to a kernel
+    bool published; // the pending read is a kernel's store (ya_grid_build_sorted_begin_publish), not a copy
+    hipStream_t stream;
 };
 
 int ya_n_reader_create(ya_n_reader** out)
@@ -889,7 +910,11 @@ int ya_n_reader_create(ya_n_reader** out)
     if (!out) return (int)hipErrorInvalidValue;
     ya_n_reader* r = (ya_n_reader*)calloc(1, sizeof(ya_n_reader));
     if (!r) return (int)hipErrorOutOfMemory;
-    hipError_t e = hipHostMalloc((void**)&r->h_n, sizeof(int), hipHostMallocDefault);
+    hipError_t e = hipHostMalloc((void**)&r->h_n, 2 * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent);
+    if (e == hipSuccess) {
+        r->h_n[0] = r->h_n[1] = 0;
+        e = hipHostGetDevicePointer((void**)&r->d_view, r->h_n, 0);
+    }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&r->done, hipEventDisableTiming);
     if (e != hipSuccess) {
         if (r->h_n) (void)hipHostFree(r->h_n);
@@ -911,12 +936,29 @@ int ya_n_read_begin(ya_n_reader* r, const int* d_n, void* stream)
 {
     if (!r || !d_n) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
+    r->published = false;
     YA_TRY(hipMemcpyAsync(r->h_n, d_n, sizeof(int), hipMemcpyDeviceToHost, st));
     return (int)hipEventRecord(r->done, st);
 }
 int ya_n_read_end(ya_n_reader* r, int* n_out)
 {
     if (!r || !n_out) return (int)hipErrorInvalidValue;
+    if (r->published) {
+        // the binning kernel's first thread stores {n, seq}: spin on the sequence number (the kernel is at
+        // most a few microseconds away); a stream that fails instead of running it ends the wait with its error
+        r->published = false;
+        for (long spins = 0;; spins++) {
+            if (__atomic_load_n(&r->h_n[1], __ATOMIC_ACQUIRE) == r->seq) break;
+            if (spins >= 2000000 && (spins & 0xfffff) == 0) {  // ~ms of spinning: is the stream still alive?
+                const hipError_t e = hipStreamQuery(r->stream);
+                if (e != hipSuccess && e != hipErrorNotReady) return (int)e;
+                if (e == hipSuccess && __atomic_load_n(&r->h_n[1], __ATOMIC_ACQUIRE) != r->seq)
+                    return (int)hipErrorUnknown;  // the stream drained and the kernel never published
+            }
+        }
+        *n_out = __atomic_load_n(&r->h_n[0], __ATOMIC_RELAXED);
+        return 0;
+    }
     YA_TRY(hipEventSynchronize(r->done));
     *n_out = *r->h_n;
     return 0;
@@ -1035,7 +1077,7 @@ static void launch_scan(ya_grid* g, int n, const int* d_n, hipStream_t st)
     const int first = range_only ? g->range_first_tile : 0;
     const int tiles = range_only ? g->range_end_tile - g->range_first_tile : g->n_tiles;
     k_scan<<<tiles, BLOCK, 0, st>>>(g->d_count, g->d_tile_state, g->d_scan_epoch, g->n_cubes, n, g->d_offs, g->d_cube_start,
-        g->d_cube_end, d_n, first, g->n_tiles);
+        g->d_cube_end, d_n, first, g->n_tiles, g->d_status);
     if (!range_only && g->range_first_tile >= 0) g->range_n = d_n ? -1 : n;
 }
 
@@ -1043,7 +1085,7 @@ static void launch_scan(ya_grid* g, int n, const int* d_n, hipStream_t st)
 // read on the device (n_bound only sizes the launches), so these kernels can be queued
 // before the host knows n.
 static int build_begin(ya_grid* g, const void* d_X, size_t stride_bytes, const int* d_n,
-    int n_bound, float cube_size, bool with_stash, hipStream_t st)
+    int n_bound, float cube_size, bool with_stash, hipStream_t st, ya_n_reader* reader = nullptr)
 {
     const int stride_f = (int)(stride_bytes / 4);
     // the previous order is worth visiting unless the population collapsed (judged by
@@ -1063,10 +1105,22 @@ static int build_begin(ya_grid* g, const void* d_X, size_t stride_bytes, const i
         }
         stash = g->d_stash;
     }
+    if (reader) {
+        if (n_bound > 0) {  // the count travels in the binning kernel itself
+            reader->seq = reader->seq == 0x7fffffff ? 1 : reader->seq + 1;
+            reader->published = true;
+            reader->stream = st;
+        } else {
+            const int rc = ya_n_read_begin(reader, d_n, st);
+            if (rc) return rc;
+            reader = nullptr;
+        }
+    }
     if (n_bound > 0)
         k_bin<<<nb_visit, BLOCK, 0, st>>>((const float*)d_X, stride_f, n_bound, cube_size,
             g->grid_size, g->n_cubes, g->d_prev_pid, n_prev, g->d_cube_of, g->d_rank, g->d_count,
-            g->d_status, stash, stride_f, d_n, g->range_lo, g->range_hi);
+            g->d_status, stash, stride_f, d_n, g->range_lo, g->range_hi, reader ? reader->d_view : nullptr,
+            reader ? reader->seq : 0);
     launch_scan(g, n_bound, d_n, st);
     if (n_bound > 0)
         k_scatter<<<nb_visit, BLOCK, 0, st>>>(g->d_cube_of, g->d_rank, g->d_offs, n_bound,
@@ -1144,6 +1198,14 @@ int ya_grid_build_sorted_begin(ya_grid* g, const void* d_X, size_t stride_bytes,
     if (!g || !d_n || n_bound < 0 || n_bound > g->n_max || stride_bytes < 12 || stride_bytes % 4)
         return (int)hipErrorInvalidValue;
     return build_begin(g, d_X, stride_bytes, d_n, n_bound, cube_size, true, (hipStream_t)stream);
+}
+
+int ya_grid_build_sorted_begin_publish(ya_grid* g, const void* d_X, size_t stride_bytes, const int* d_n,
+    int n_bound, float cube_size, ya_n_reader* reader, void* stream)
+{
+    if (!g || !d_n || !reader || n_bound < 0 || n_bound > g->n_max || stride_bytes < 12 || stride_bytes % 4)
+        return (int)hipErrorInvalidValue;
+    return build_begin(g, d_X, stride_bytes, d_n, n_bound, cube_size, true, (hipStream_t)stream, reader);
 }
 
 int ya_grid_build_sorted_finish(ya_grid* g, const void* d_X, size_t stride_bytes,
