@@ -848,6 +848,9 @@ __device__ __forceinline__ void pass(const Entry<Pt>* __restrict__ sh_e, const f
         YA_CALL_INLINED F += pw_int(Xi, r, dist, i, j);                                \
         pair_friction<Pt, pw_friction>(Xi, r, dist, i, j, v_, sum_v, sum_friction);    \
     }
+#ifdef YA_BITS_MEASUREMENT_PROBES  // measurement builds only (tools/micro/force_ab.hip; -Itools/ab): the balance and phase-1 probes
+#include "bits_probe.inc"
+#endif
     while (cur != 0 || left > 0) {
         const bool refill = cur == 0;  // then left > 0
         cur = refill ? nxt : cur;
