@@ -226,7 +226,7 @@ def kernel_source_sha():
 
 
 def counters_key(args, n_total):
-    """Key of this workload in profiles/r05_counters.json (None: no counters kept for it)."""
+    """Key of this workload in profiles/r06_counters.json (None: no counters kept for it)."""
     if args.slab or args.gpus > 1 or args.force_variant not in (-1, 2):
         return None
     tier = "" if args.arith == "exact" else "_fast"
@@ -246,11 +246,11 @@ def counters_key(args, n_total):
 
 def measured_counters(kernel_key):
     """Per-launch PMC figures of the dominant kernel from the committed rocprofv3 passes of
-    this same command (profiles/r05_counters.json, written by tools/roofline_json.py):
+    this same command (profiles/r06_counters.json, written by tools/roofline_json.py):
     HBM-side traffic (FETCH_SIZE and WRITE_SIZE from separate --pmc passes, KiB, FETCH_SIZE
     doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950) and the
     ceilings that bind this kernel.  Returns ({}, None) when there is no record."""
-    path = os.path.join(ROOT, "profiles", "r05_counters.json")
+    path = os.path.join(ROOT, "profiles", "r06_counters.json")
     try:
         with open(path) as f:
             rec = json.load(f)[kernel_key]
@@ -263,7 +263,7 @@ def measured_counters(kernel_key):
     head = {"commit": rec.get("head"), "kernel_sha": rec.get("kernel_sha")}
     if rec.get("kernel_sha") != kernel_source_sha():
         # measured on an older kernel: do not pass the numbers off as this build's
-        sys.stderr.write("bench.py: profiles/r05_counters.json[%s] was measured on another kernel source "
+        sys.stderr.write("bench.py: profiles/r06_counters.json[%s] was measured on another kernel source "
                          "(%s != %s); traffic and PMC fractions omitted\n" % (kernel_key, rec.get("kernel_sha"), kernel_source_sha()))
         return {"stale_counters": True}, head
     return out, head
@@ -616,7 +616,19 @@ def main(argv=None):
         scratch.random_sphere(args.dist, 42)
         return scratch
 
-    scratch, preheat_facts = preheat(slab_scratch if slab_path else make_sim)
+    def headline_scratch(sum_order=None):
+        """The scratch copy of the headline run steps the SAME positions with the clipped_spring functor (the same
+        force for every pair inside the cut-off, another template instantiation): rocprofv3's per-kernel averages of
+        `grid_force_bits<float3, spring, ...>` then hold the warm-up and measured launches only, not the preheat's."""
+        scratch = Solution("clipped_grid", n_total, gs, 1.0)
+        scratch.random_sphere(args.dist, 42)
+        scratch.set_param("force_variant", args.force_variant)
+        if (args.sum_order if sum_order is None else sum_order):
+            scratch.set_param("sum_order", 1)
+        return scratch
+
+    springs_headline = args.model == "springs_grid" and state is None and not slab_path
+    scratch, preheat_facts = preheat(slab_scratch if slab_path else headline_scratch if springs_headline else make_sim)
     advance(args.warmup)
     barrier()
     # The engine replays small systems' steps as a hipGraph (Heun_solver::graph_steps), which
@@ -688,7 +700,7 @@ def main(argv=None):
         sim = make_sim(sum_order=sum_order)
         thread, stop, samples = start_clock_sampler(0.002)
         sim.profile(True, every=1)
-        scratch, _ = preheat(lambda: make_sim(sum_order=sum_order))
+        scratch, _ = preheat((lambda: headline_scratch(sum_order)) if springs_headline else (lambda: make_sim(sum_order=sum_order)))
         advance(args.warmup)
         barrier()
         sim.profile_read()   # (the warm-up's launches: dropped)

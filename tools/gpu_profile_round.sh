@@ -16,7 +16,7 @@ esac
 timeout 900 python bench.py "$@" $state > $out/bench.json 2> $out/bench.err
 cat $out/bench.json
 cd /tmp && export TMPDIR=/tmp
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o k -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-fast-tier-line --no-sustained-line "$@" $state > $out/stats_bench.json 2> $out/stats.err
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o k -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-fast-tier-line --no-sustained-line --no-tail-ab-line "$@" $state > $out/stats_bench.json 2> $out/stats.err
 i=0
 for pass in "FETCH_SIZE" "WRITE_SIZE" \
   "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS" \
@@ -25,7 +25,7 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" \
   "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum" \
   "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
   i=$((i+1))
-  timeout 600 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $out/pmc$i -o p -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-fast-tier-line --no-sustained-line --steps 10 --warmup 2 "$@" $state > $out/pmc$i.json 2> $out/pmc$i.err
+  timeout 600 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $out/pmc$i -o p -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-fast-tier-line --no-sustained-line --no-tail-ab-line --preheat-ms 50 --steps 10 --warmup 2 "$@" $state > $out/pmc$i.json 2> $out/pmc$i.err
 done
 python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py "$out/pmc*/*counter_collection.csv" grid_force > $out/pmc_summary.txt
 python3 $GRAFT_REPO_ROOT/tools/roofline_json.py $out $out/counters.json $key "$*" $head > $out/counters.log 2>&1

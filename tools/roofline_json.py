@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
-"""One entry of profiles/r05_counters.json from the rocprofv3 PMC passes of a bench.py command
+"""One entry of profiles/r06_counters.json from the rocprofv3 PMC passes of a bench.py command
 (tools/gpu_profile_round.sh): per-launch means for the dominant kernel (grid_force_bits).
 
     python tools/roofline_json.py gpurun_out/<tag> <out.json> <key> "<bench args>" [commit]
 
 (tools/gpu_profile_round.sh runs it on the GPU box; tools/merge_counters.py folds the entries into
-profiles/r05_counters.json)
+profiles/r06_counters.json)
 
-Definitions (every input is a raw counter kept in profiles/r05_pmc_<key>.txt):
+Definitions (every input is a raw counter kept in profiles/r06_pmc_<key>.txt):
   kernel_cycles       GRBM_GUI_ACTIVE / 8                 (the counter sums the 8 XCDs)
   clock_ghz           kernel_cycles / the kernel's average duration in the same pass
   valu_insts_per_wave SQ_INSTS_VALU / SQ_WAVES
