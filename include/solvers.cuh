@@ -1727,51 +1727,16 @@ __global__ __launch_bounds__(ya::UPDATE_BLOCK) void ghosts_into_sorted(const int
 // (dtypes.cuh:202-217), hence the same bits as ya_reduce_mean leaves in d_mean -- only x, y, z, all the
 // update kernels subtract (solvers.cuh:113-144).
 namespace ya {
-// Round 6, small systems: up to this many partial sums (n <= 256 x this many cells) are not produced by a launch of
-// their own (ya_reduce_partials: 4.4 us of launch floor for a few thousand additions) but by every workgroup of the
-// update kernel itself, straight from the right-hand sides (`rows`): block b's partial sum is k_reduce_partial's --
-// lane t holds 0 + row[256 b + t] (one row per lane while n <= 256 B), the 256 lanes folded by halving -- computed by
-// ONE wavefront that holds four of the block's lanes per lane: lane[t] += lane[t + 128] and lane[t] += lane[t + 64]
-// are register adds, the rest the same shuffles.  The same operands in the same order: the same bits.
-constexpr int FOLD_INLINE_MAX_PARTIALS = 64;
 template<int NF>
 __device__ __forceinline__ float3 fixed_velocity_from_partials(const float* __restrict__ partials, const int n_partials,
-    const int n, const float* __restrict__ rows = nullptr)
+    const int n)
 {
     static_assert(UPDATE_BLOCK == 256, "the fold is libyalla_hip.so's fold256");
     __shared__ float sh[3 * UPDATE_BLOCK];
     float acc[3] = {0.f, 0.f, 0.f};
-    if (rows) {  // (workgroup-uniform)
-        __shared__ float sh_part[3 * FOLD_INLINE_MAX_PARTIALS];
-        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-        for (int b = wave; b < n_partials; b += UPDATE_BLOCK / 64) {
-            float r[4][3];
+    for (int p = threadIdx.x; p < n_partials; p += UPDATE_BLOCK) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int i = b * UPDATE_BLOCK + lane + 64 * j;
-#pragma unroll
-                for (int k = 0; k < 3; k++) r[j][k] = i < n ? 0.f + rows[(size_t)i * NF + k] : 0.f;
-            }
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                r[0][k] = r[0][k] + r[2][k];  // lane[t] += lane[t + 128], t = lane
-                r[1][k] = r[1][k] + r[3][k];  //                           t = lane + 64
-                float v = r[0][k] + r[1][k];  // lane[t] += lane[t + 64]
-#pragma unroll
-                for (int s2 = 32; s2 >= 1; s2 >>= 1) v = v + __shfl_down(v, s2, 64);
-                if (lane == 0) sh_part[k * FOLD_INLINE_MAX_PARTIALS + b] = v;
-            }
-        }
-        __syncthreads();
-        if ((int)threadIdx.x < n_partials) {
-#pragma unroll
-            for (int k = 0; k < 3; k++) acc[k] = acc[k] + sh_part[k * FOLD_INLINE_MAX_PARTIALS + threadIdx.x];
-        }
-    } else {
-        for (int p = threadIdx.x; p < n_partials; p += UPDATE_BLOCK) {
-#pragma unroll
-            for (int k = 0; k < 3; k++) acc[k] = acc[k] + partials[(size_t)p * NF + k];
-        }
+        for (int k = 0; k < 3; k++) acc[k] = acc[k] + partials[(size_t)p * NF + k];
     }
 #pragma unroll
     for (int k = 0; k < 3; k++) sh[k * UPDATE_BLOCK + threadIdx.x] = acc[k];
@@ -1807,10 +1772,9 @@ __device__ __forceinline__ float3 fixed_velocity_from_partials(const float* __re
 template<typename Pt>
 __global__ __launch_bounds__(ya::UPDATE_BLOCK) void euler_step_sorted_folding(const int n, const float dt,
     const float* __restrict__ partials, const int n_partials, float* __restrict__ d_fix_out,
-    const Pt* __restrict__ d_dX_sorted, ya::Entry<Pt>* __restrict__ d_sorted, const Pt* __restrict__ rows)
+    const Pt* __restrict__ d_dX_sorted, ya::Entry<Pt>* __restrict__ d_sorted)
 {
-    const float3 fix = ya::fixed_velocity_from_partials<ya::N_floats<Pt>::value>(partials, n_partials, n,
-        reinterpret_cast<const float*>(rows));
+    const float3 fix = ya::fixed_velocity_from_partials<ya::N_floats<Pt>::value>(partials, n_partials, n);
     const int s = blockIdx.x * ya::UPDATE_BLOCK + threadIdx.x;
     if (s == 0) {
         d_fix_out[0] = fix.x;
@@ -1838,7 +1802,6 @@ __global__ __launch_bounds__(ya::UPDATE_BLOCK) void euler_step_folding(const int
     Pt* __restrict__ d_dX, Pt* __restrict__ d_X, const Pt* __restrict__ d_dX_sorted, ya::Entry<Pt>* __restrict__ d_sorted,
     Pt* __restrict__ d_zero)
 {
-    // (no inline partial sums here: this kernel REWRITES d_dX, the rows another workgroup would still be summing)
     const float3 fix = ya::fixed_velocity_from_partials<ya::N_floats<Pt>::value>(partials, n_partials, n);
     const int i = blockIdx.x * ya::UPDATE_BLOCK + threadIdx.x;
     if (i == 0) {
@@ -1894,11 +1857,9 @@ __global__ __launch_bounds__(ya::UPDATE_BLOCK) void heun_step_folding(const int 
 template<typename Pt>
 __global__ __launch_bounds__(ya::UPDATE_BLOCK) void heun_step_raw_folding(const int n, const float dt,
     const Pt* __restrict__ d_dX, const float* __restrict__ d_fix, const Pt* __restrict__ d_dX1,
-    const float* __restrict__ partials1, const int n_partials1, Pt* __restrict__ d_X, float3* __restrict__ d_old_v,
-    const bool inline_partials)
+    const float* __restrict__ partials1, const int n_partials1, Pt* __restrict__ d_X, float3* __restrict__ d_old_v)
 {
-    const float3 fix1 = ya::fixed_velocity_from_partials<ya::N_floats<Pt>::value>(partials1, n_partials1, n,
-        inline_partials ? reinterpret_cast<const float*>(d_dX1) : nullptr);
+    const float3 fix1 = ya::fixed_velocity_from_partials<ya::N_floats<Pt>::value>(partials1, n_partials1, n);
     const int i = blockIdx.x * ya::UPDATE_BLOCK + threadIdx.x;
     if (i >= n) return;
 
@@ -2284,8 +2245,6 @@ protected:
     // sorted-space step with set_fixed(): the update kernels fold the reductions' partial sums themselves
     // (ya::fixed_velocity_from_partials; false = ya_reduce_mean's second launch, A/B)
     bool fold_in_update = true;
-    // ... and, up to 64 x 256 cells, sum the per-block partial sums themselves too (false: ya_reduce_partials' launch, A/B)
-    bool inline_small_reductions = true;
     int fix_point = 0;
     const int n_max;
     int get_d_n()
@@ -2489,19 +2448,13 @@ protected:
         if (fix_com and !fix_com_z and fold_in_update) {
             // set_fixed() (the default): both fixed velocities are means, folded by the update kernels
             // themselves from the reductions' partial sums (two launches fewer; same bits)
-            // Small systems (round 6): the update kernels sum the <= 64 per-block partial sums themselves, straight from
-            // the right-hand sides (ya::fixed_velocity_from_partials, `rows`): two launches fewer per step.  Neither
-            // kernel writes the array it sums (the folding kernels of the d_X / d_X1 pipeline do: not there).
-            const int blocks_of_rows = (n + 255) / 256;
-            const bool inline_partials = blocks_of_rows <= ya::FOLD_INLINE_MAX_PARTIALS && inline_small_reductions;
-            int n_partials = blocks_of_rows;
-            if (!inline_partials) YA_CHECK(ya_reduce_partials(d_dX, n_floats, n, d_workspace, &n_partials, this->stream));
-            Computer<Pt>::predictor_in_sorted_space_folding(n, dt, d_workspace, n_partials, d_mean_first,
-                inline_partials ? d_dX : nullptr);
+            int n_partials = 0;
+            YA_CHECK(ya_reduce_partials(d_dX, n_floats, n, d_workspace, &n_partials, this->stream));
+            Computer<Pt>::predictor_in_sorted_space_folding(n, dt, d_workspace, n_partials, d_mean_first);
             Computer<Pt>::template pwints_from_sorted<pw_int, pw_friction>(n, d_dX1, n, false);
-            if (!inline_partials) YA_CHECK(ya_reduce_partials(d_dX1, n_floats, n, d_workspace, &n_partials, this->stream));
+            YA_CHECK(ya_reduce_partials(d_dX1, n_floats, n, d_workspace, &n_partials, this->stream));
             heun_step_raw_folding<<<blocks, ya::UPDATE_BLOCK, 0, this->stream>>>(
-                n, dt, d_dX, d_mean_first, d_dX1, d_workspace, n_partials, d_X, d_old_v, inline_partials);
+                n, dt, d_dX, d_mean_first, d_dX1, d_workspace, n_partials, d_X, d_old_v);
             return;
         }
         // this stage's fixed velocity has to outlive the next reduction
@@ -2644,7 +2597,7 @@ protected:
     const int* cube_order(int, const Pt*) { return nullptr; }  // no grid: renumber() is a no-op
     void ids_changed() {}
     void predictor_in_sorted_space(int, float, const float*, int) {}
-    void predictor_in_sorted_space_folding(int, float, const float*, int, float*, const Pt*) {}
+    void predictor_in_sorted_space_folding(int, float, const float*, int, float*) {}
     const Pt* sorted_rhs() const { return nullptr; }
     ya::Entry<Pt>* sorted_cells() { return nullptr; }
     void predictor_in_sorted_space_mirrored(int, float, const float*, float*, int, const Pt*, int, float*, ya::Guard_band) {}
@@ -3122,10 +3075,10 @@ protected:
     const Pt* sorted_rhs() const { return d_dX_sorted; }
     ya::Entry<Pt>* sorted_cells() { return d_sorted; }
     void predictor_in_sorted_space_folding(const int n, const float dt, const float* d_partials, const int n_partials,
-        float* d_fix_out, const Pt* d_rows)
+        float* d_fix_out)
     {
         euler_step_sorted_folding<<<(n + ya::UPDATE_BLOCK - 1) / ya::UPDATE_BLOCK, ya::UPDATE_BLOCK, 0, stream>>>(
-            n, dt, d_partials, n_partials, d_fix_out, d_dX_sorted, d_sorted, d_rows);
+            n, dt, d_partials, n_partials, d_fix_out, d_dX_sorted, d_sorted);
     }
     void predictor_in_sorted_space_mirrored(const int n, const float dt, const float* d_total, float* d_fix_out,
         const int n_active, const Pt* d_dX, const int fix_mode, float* pred_partial, const ya::Guard_band band)

@@ -183,31 +183,6 @@ def test_force_kernels_agree_on_dense_rows(device, model, n, dist, cube):
             assert np.array_equal(res[order][0][1].view(np.uint32), v.view(np.uint32))
 
 
-@pytest.mark.parametrize("model,n", [("springs_grid", 300), ("springs_grid", 10000), ("springs_grid", 16384),
-                                     ("springs_grid", 16385), ("relu_po_grid", 5000), ("sorting_grid", 10000)])
-def test_small_systems_sum_their_partial_sums_in_the_update_kernels(oracle, device, model, n):
-    """Up to 64 x 256 cells the update kernels of the sorted-space step compute the centre-of-mass reduction's
-    per-block partial sums themselves (ya::fixed_velocity_from_partials with `rows`; round 6) instead of reading
-    them from ya_reduce_partials' launch (sorted_pipeline 3): the same tree, the same bits -- and the oracle's."""
-    res = []
-    for pipeline in (1, 3):
-        with Solution(model, n, 50, 1.0, lib=device) as s:
-            s.random_sphere(0.5, 21)
-            if model.startswith("sorting"):
-                s.set_param("n_cells", n)
-            s.set_param("sorted_pipeline", pipeline)
-            s.take_step(0.002, 3)
-            res.append((s.positions(), s.old_v()))
-    assert np.array_equal(res[0][0].view(np.uint32), res[1][0].view(np.uint32))
-    assert np.array_equal(res[0][1].view(np.uint32), res[1][1].view(np.uint32))
-    if not model.startswith("sorting"):   # (powf: tolerance only against the oracle)
-        with Solution(model, n, 50, 1.0, lib=oracle) as s:
-            s.set_reduce_order(1)
-            s.random_sphere(0.5, 21)
-            s.take_step(0.002, 3)
-            assert np.array_equal(res[0][0].view(np.uint32), s.positions().view(np.uint32))
-
-
 def test_both_second_stage_pipelines_agree(oracle, device):
     """The second Heun stage built from the cube-sorted cells (default) and from d_X1
     (the reference's structure) are the same arithmetic: bit-identical positions,
