@@ -1,0 +1,120 @@
+"""An INDEPENDENT binary32 statement of the reference's grid-force sum, written in numpy from the reference alone
+(include/solvers.cuh:430-463 `compute_cube`, :472-483 the stencil table, :349-365 the cube id; examples/springs.cu:14-21
+the functor; include/dtypes.cuh:150-217 the operators) -- one running sum per cell over the 27 cubes in d_nhood
+order, cells of a cube in ascending id -- held bit for bit against
+
+  * the oracle's default (YA_SUM_REFERENCE) on the CPU, and its second mode (YA_SUM_BY_PLANE) against the same
+    statement with the two partial sums;
+  * the HIP engine's default and its opt-in order on the GPU.
+
+How a force becomes observable bit for bit: one take_step with dt = 0 and set_fixed(p), p a lone cell far from all
+others (its force is exactly 0).  Both stages then see the same positions and old_v = 0, the fixed velocity is
+dX[p] = 0, and heun_step leaves old_v = ((F - 0) + (F - 0)) * 0.5 = F exactly (solvers.cuh:113-144).
+
+Arithmetic as the oracle's header states it: r = Xi - Xj, dist = sqrtf(fmaf(z, z, fmaf(y, y, x * x))),
+r * (0.5 - dist) componentwise, then `/ dist` = `* float(1. / dist)` (dtypes.cuh:202-208).  fmaf is emulated through
+binary64 (the product of two binary32 numbers is exact there)."""
+import numpy as np
+import pytest
+
+from yalla_amd.solution import Solution
+
+f32 = np.float32
+GS = 30
+
+
+def fma32(a, b, c):
+    return f32(np.float64(a) * np.float64(b) + np.float64(c))
+
+
+def system(n=260, seed=3):
+    rng = np.random.default_rng(seed)
+    X = (rng.random((n, 3)) * 4.6 - 2.3).astype(f32)          # ~2.7 cells per unit cube ... dense enough for
+    X[: n // 3] = (rng.random((n // 3, 3)) * 2.0 - 1.0).astype(f32)   # ... ~12 in the middle
+    X[-1] = (9.5, 8.5, 7.5)                                    # the lone cell that is held fixed
+    return X
+
+
+def reference_forces(X, by_plane):
+    """F[i] exactly as the reference's thread accumulates it (or in the two partial sums of YA_SUM_BY_PLANE)."""
+    n = len(X)
+    cube3 = np.floor(X).astype(np.int64) + GS // 2             # cube_size 1 (solvers.cuh:357-360; exact below 2^24)
+    cube = cube3[:, 0] + cube3[:, 1] * GS + cube3[:, 2] * GS * GS
+    members = {}
+    for i in np.argsort(cube, kind="stable"):                  # stable sort: ascending id inside a cube
+        members.setdefault(int(cube[i]), []).append(int(i))
+    h = [-1, 0, 1]                                             # solvers.cuh:472-483
+    h = h + [h[i % 3] - GS for i in range(3)] + [h[i % 3] + GS for i in range(3)]
+    h = h + [h[i % 9] - GS * GS for i in range(9)] + [h[i % 9] + GS * GS for i in range(9)]
+    F = np.zeros((n, 3), f32)
+    for i in range(n):
+        acc = np.zeros(3, f32)
+        own = np.zeros(3, f32)
+        for jn, off in enumerate(h):
+            if by_plane and jn == 9:
+                own, acc = acc, np.zeros(3, f32)
+            for k in members.get(int(cube[i]) + off, ()):
+                r = X[i] - X[k]                                 # a += -1 * b, componentwise binary32
+                d2 = fma32(r[2], r[2], fma32(r[1], r[1], f32(r[0] * r[0])))
+                dist = np.sqrt(d2)                              # correctly rounded binary32
+                if dist >= f32(1.0):                            # :450
+                    continue
+                if k == i:                                      # springs.cu:17
+                    continue
+                s = f32(0.5) - dist
+                inv = f32(np.float64(1.0) / np.float64(dist))   # `a *= 1. / b` (dtypes.cuh:204-208)
+                acc = acc + (r * s) * inv
+        F[i] = own + acc if by_plane else acc
+    return F
+
+
+def forces_of(lib, X, sum_order):
+    n = len(X)
+    with Solution("springs_grid", n, GS, 1.0, lib=lib) as s:
+        s.h_X[:n] = X
+        s.h_n = n
+        s.copy_to_device()
+        if sum_order:
+            s.set_param("sum_order", sum_order)
+        s.set_fixed(n - 1)
+        s.take_step(0.0, 1)
+        assert np.array_equal(s.positions().view(np.uint32), X.view(np.uint32))   # dt = 0: nothing moved
+        return s.old_v()[:n].copy()
+
+
+@pytest.mark.parametrize("sum_order", [0, 1])
+def test_oracle_sums_as_the_reference_thread_does(oracle, sum_order):
+    X = system()
+    F = reference_forces(X, by_plane=bool(sum_order))
+    got = forces_of(oracle, X, sum_order)
+    assert np.abs(F).max() > 1 and (F[-1] == 0).all()
+    assert np.array_equal(F.view(np.uint32), got.view(np.uint32))
+
+
+def test_the_two_orders_are_different_roundings_of_the_same_sum(oracle):
+    X = system()
+    a, b = reference_forces(X, False), reference_forces(X, True)
+    assert not np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert np.abs(a - b).max() <= 4e-6 * np.abs(a).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sum_order", [0, 1])
+def test_engine_sums_as_the_reference_thread_does(device, sum_order):
+    """The HIP engine's default order IS the reference's (and its opt-in order the by-plane statement), bit for bit
+    against numpy -- no oracle in between."""
+    X = system()
+    F = reference_forces(X, by_plane=bool(sum_order))
+    for variant in (-1, 2, 3, 0, 1):   # the engine's choice, bit stream, several lanes per cell, direct, byte FIFO
+        n = len(X)
+        with Solution("springs_grid", n, GS, 1.0, lib=device) as s:
+            s.h_X[:n] = X
+            s.h_n = n
+            s.copy_to_device()
+            s.set_param("force_variant", variant)
+            if sum_order:
+                s.set_param("sum_order", sum_order)
+            s.set_fixed(n - 1)
+            s.take_step(0.0, 1)
+            got = s.old_v()[:n].copy()
+        assert np.array_equal(F.view(np.uint32), got.view(np.uint32)), variant
