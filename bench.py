@@ -925,12 +925,15 @@ def main(argv=None):
             # sources (what nvcc's default contraction and norm3df give the reference's own CUDA build)
             sim.close()
             with make_sim(lib=_ffi.device_lib("fast")) as fast:
+                scratch, _ = preheat(headline_scratch)   # (as the headline: not on an idle GPU's clock ramp)
                 fast.take_step(dt, args.warmup)
                 fast.synchronize()
                 t1 = time.perf_counter()
                 fast.take_step(dt, args.steps)
                 fast.synchronize()
                 fast_s = time.perf_counter() - t1
+                if scratch is not None:
+                    scratch.close()
             out["fast_arith_tier"] = {
                 "value": n_total * args.steps / fast_s, "unit": "cell-updates/s", "ms_per_step": fast_s / args.steps * 1e3,
                 "what": "libyalla_models_fast.so: the same sources with -DYA_ARITH_FAST -ffp-contract=fast (bare v_sqrt_f32 / "

@@ -29,7 +29,7 @@ def test_core_library_exports_every_declared_symbol():
     for name in names:
         assert hasattr(lib, name), name
     lib.ya_abi_version.restype = ctypes.c_int
-    assert lib.ya_abi_version() == 9
+    assert lib.ya_abi_version() == 10
     lib.ya_reduce_workspace_bytes.restype = ctypes.c_size_t
     assert lib.ya_reduce_workspace_bytes(3) == 1024 * 3 * 4
 
