@@ -239,6 +239,7 @@ int main(int argc, char** argv)
     double whole_ms;
     {
         Solution<float3, Grid_solver> whole{n, gs, 1.f};
+        if (getenv("YALLA_SUM_ORDER") && atoi(getenv("YALLA_SUM_ORDER")) == 1) whole.sum_order = YA_SUM_BY_PLANE;  // (opt-in order: half tiles)
         random_sphere(dist, whole, 0, 42);
         std::copy(whole.h_X, whole.h_X + n, X0.begin());
         for (int s = 0; s < warmup; s++) one_step(whole, dt);
@@ -274,6 +275,7 @@ int main(int argc, char** argv)
         if (interior) s.slab_use_interior_stream(interior);
         if (s.slab_adopt(plan, r, X0.data(), n, s.h_X, s.h_n) != 0) return 2;
         s.d_global_id = nullptr;  // spring only compares i with j (as bench.py runs it)
+        if (getenv("YALLA_SUM_ORDER") && atoi(getenv("YALLA_SUM_ORDER")) == 1) s.sum_order = YA_SUM_BY_PLANE;
         ranks[r].shared = &shared;
         ranks[r].rank = r;
         s.slab_set_transport(exchange_cb, allreduce_cb, &ranks[r]);
