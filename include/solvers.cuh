@@ -679,21 +679,23 @@ namespace ya {
 // Results are bit-identical to the earlier kernels' (tools/ab/force_variants.cuh): same candidates, same
 // order, same arithmetic.
 // The friction terms of one pair (solvers.cuh:309-313, :453-458): sum_friction += friction,
-// sum_v += friction * old_v[j].  For the default functor friction_w_neighbour the coefficient
-// is 0 or 1, so the products are selections: `+= nb ? v : +0` gives the bits of the reference's
-// `if (friction != 0) sum += 1.f * v` (1.f * v is v; adding +0 to a sum that started at +0
-// never changes it: such a sum cannot be -0) in 8 instead of 14 instructions per pair
-// (-2.6 % on the 1 M-cell force launch, profiles/r03_force_ab.jsonl).
+// sum_v += friction * old_v[j].  For the default functor friction_w_neighbour the coefficient f
+// is 0 or 1, so f * v is exact and `fmaf(f, v, sum)` is `sum + f * v` with its one rounding: the
+// reference's bits, unconditionally as the reference adds it (a non-finite old_v poisons the sum
+// there and here), in one instruction per component where `sum += nb ? v : 0` took two (round 6:
+// 242 -> 237 us per 1 M-cell launch, profiles/r06_force_ab.jsonl; round 3's selections had been
+// -2.6 % against the multiply-and-add before them).
 template<typename Pt, Pairwise_friction<Pt> pw_friction>
 __device__ __forceinline__ void pair_friction(const Pt& Xi, const Pt& r, const float dist, const int i,
     const int j, const float4& v, float3& sum_v, float& sum_friction)
 {
     if constexpr (pw_friction == &friction_w_neighbour<Pt>) {
         const bool nb = (i != j) & (dist < 1.f);
-        sum_friction += nb ? 1.f : 0.f;
-        sum_v.x += nb ? v.x : 0.f;
-        sum_v.y += nb ? v.y : 0.f;
-        sum_v.z += nb ? v.z : 0.f;
+        const float f = nb ? 1.f : 0.f;
+        sum_friction += f;
+        sum_v.x = fmaf(f, v.x, sum_v.x);
+        sum_v.y = fmaf(f, v.y, sum_v.y);
+        sum_v.z = fmaf(f, v.z, sum_v.z);
     } else {
         const float friction = pw_friction(Xi, r, dist, i, j);
         sum_friction += friction;
