@@ -47,3 +47,13 @@ def scheme(H,delta,LIST=10,EVAL=85,ADD=10,FIX=60):
 for d in (-1,0,1,2,3,4):
     t=scheme(H,d)
     print("delta %+d: scheme %.0f  ratio %.3f"%(d,t.mean(),t.mean()/cur.mean()))
+
+# regrouping: blocks of 256 consecutive cells, sorted by total hits, dealt to 4 waves; one running pass over all planes
+T4=(len(H)//4)*4
+B=H[:T4].reshape(-1,4,64,3)
+tot=B.sum(3).reshape(len(B),256)
+tot_sorted=np.sort(tot,axis=1)[:,::-1].reshape(len(B),4,64)
+regroup=(np.ceil(tot_sorted.max(2)/2)*2*PAIR).sum(1)            # per block of 4 waves
+cur4=(np.ceil(B.max(2)/2)*2*PAIR).sum(2).sum(1)
+merged=(np.ceil(B.sum(3).max(2)/2)*2*PAIR).sum(1)               # merged planes only, no regrouping
+print("per 256 cells: current %.0f  merged planes %.0f (%.3f)  regrouped+merged %.0f (%.3f)  ideal %.0f"%(cur4.mean(), merged.mean(), merged.mean()/cur4.mean(), regroup.mean(), regroup.mean()/cur4.mean(), (np.ceil(tot.mean(1)/2)*2*PAIR*4).mean()))
