@@ -126,7 +126,11 @@ def test_other_example_programs_run(tmp_path, name):
         from mesh_fixtures import write_sphere_ic
         (tmp_path / "examples").mkdir()
         write_sphere_ic(tmp_path / "examples" / "sphere_ic.vtk")
-    frames = run_model(name, tmp_path)
+    # model_features_sequential_addition.cu seeds its proliferation with time(NULL) (:261) and has no guard on
+    # n_cells reaching its own n_max = 4000 but the assertion in copy_to_host (the reference's solvers.cuh:82,90 has
+    # the same one): one run in a few dozen grows that far and ends there -- the model's limit, not the engine's;
+    # the frames written until then are checked
+    frames = run_model(name, tmp_path, may_end_with="*h_n <= n_max" if name == "model_features_sequential_addition" else None)
     assert len(frames) >= 1
     numbered = sorted((f for f in frames if f.endswith(".vtk")),
                       key=lambda f: (f.rsplit("_", 1)[0], int(f.rsplit("_", 1)[1][:-4])))
