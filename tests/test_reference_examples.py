@@ -130,7 +130,9 @@ def test_other_example_programs_run(tmp_path, name):
     # n_cells reaching its own n_max = 4000 but the assertion in copy_to_host (the reference's solvers.cuh:82,90 has
     # the same one): one run in a few dozen grows that far and ends there -- the model's limit, not the engine's;
     # the frames written until then are checked
-    frames = run_model(name, tmp_path, may_end_with="*h_n <= n_max" if name == "model_features_sequential_addition" else None)
+    # (lineage_tracing.cu and growth_w_wall.cu proliferate on time(NULL) seeds too)
+    grows_on_the_clock = name in ("model_features_sequential_addition", "lineage_tracing", "growth_w_wall")
+    frames = run_model(name, tmp_path, may_end_with="*h_n <= n_max" if grows_on_the_clock else None)
     assert len(frames) >= 1
     numbered = sorted((f for f in frames if f.endswith(".vtk")),
                       key=lambda f: (f.rsplit("_", 1)[0], int(f.rsplit("_", 1)[1][:-4])))
