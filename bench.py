@@ -87,14 +87,14 @@ STATELESS_MODELS = ("springs_grid", "clipped_grid", "sorting_grid", "relu_grid",
                     "branching_grid", "springs_links_grid")   # YA_STATELESS in yalla_amd/csrc/model_functors.h
 
 
-def force_kernel_label(default_name, variant, n, model=""):
+def force_kernel_label(default_name, variant, n, model="", sum_order=0):
     """The force kernel a launch of n cells goes to (Grid_computer::forces, ya::coop::lanes_for)."""
     if variant < 0:
         variant = 3 if model in STATELESS_MODELS else 2
     if variant == 2 or "grid_force_bits" not in default_name:
         return default_name
     if variant == 3:
-        lanes = 16 if n <= 15000 else 8 if n <= 40000 else 4 if n <= 70000 else 1
+        lanes = 16 if n <= 15000 else 8 if n <= 40000 else 4 if n <= (70000 if sum_order else 120000) else 1
         if lanes == 1:
             return default_name
         return default_name.replace("grid_force_bits<", "grid_force_coop<").replace(">", f", {lanes} lanes per cell>")
@@ -833,7 +833,7 @@ def main(argv=None):
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": force_kernel_label(kernel_name, args.force_variant, n_total // world, args.model),
+                "kernel": force_kernel_label(kernel_name, args.force_variant, n_total // world, args.model, args.sum_order),
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

@@ -69,7 +69,9 @@ def test_defaults_follow_north_star():
     name = "ya::grid_force_bits<float3, spring, friction_w_neighbour>"
     assert "16 lanes" in bench.force_kernel_label(name, -1, 10_000, "springs_grid")
     assert "4 lanes" in bench.force_kernel_label(name, -1, 70_000, "springs_grid")
-    assert bench.force_kernel_label(name, -1, 100_000, "springs_grid") == name
+    assert "4 lanes" in bench.force_kernel_label(name, -1, 100_000, "springs_grid")       # default summation order
+    assert bench.force_kernel_label(name, -1, 100_000, "springs_grid", 1) == name          # by plane: half tiles instead
+    assert bench.force_kernel_label(name, -1, 130_000, "springs_grid") == name
 
 
 @pytest.mark.gpu
