@@ -35,8 +35,10 @@ def system(n=260, seed=3):
     return X
 
 
-def reference_forces(X, by_plane):
-    """F[i] exactly as the reference's thread accumulates it (or in the two partial sums of YA_SUM_BY_PLANE)."""
+def reference_forces(X, by_plane, old_v=None):
+    """F[i] exactly as the reference's thread accumulates it (or in the two partial sums of YA_SUM_BY_PLANE).
+    With old_v: the stage's whole right-hand side, F + sum_v / sum_friction (solvers.cuh:453-461 and add_rhs
+    :146-161) -- sum_friction += friction and sum_v += friction * old_v[k] run in the same loop, the same order."""
     n = len(X)
     cube3 = np.floor(X).astype(np.int64) + GS // 2             # cube_size 1 (solvers.cuh:357-360; exact below 2^24)
     cube = cube3[:, 0] + cube3[:, 1] * GS + cube3[:, 2] * GS * GS
@@ -50,21 +52,33 @@ def reference_forces(X, by_plane):
     for i in range(n):
         acc = np.zeros(3, f32)
         own = np.zeros(3, f32)
+        sv, sv_own = np.zeros(3, f32), np.zeros(3, f32)
+        sf, sf_own = f32(0), f32(0)
         for jn, off in enumerate(h):
             if by_plane and jn == 9:
                 own, acc = acc, np.zeros(3, f32)
+                sv_own, sv = sv, np.zeros(3, f32)
+                sf_own, sf = sf, f32(0)
             for k in members.get(int(cube[i]) + off, ()):
                 r = X[i] - X[k]                                 # a += -1 * b, componentwise binary32
                 d2 = fma32(r[2], r[2], fma32(r[1], r[1], f32(r[0] * r[0])))
                 dist = np.sqrt(d2)                              # correctly rounded binary32
                 if dist >= f32(1.0):                            # :450
                     continue
-                if k == i:                                      # springs.cu:17
+                if k == i:                                      # springs.cu:17; friction_w_neighbour: 0 (solvers.cuh:30)
                     continue
+                if old_v is not None:                           # friction_w_neighbour: 1 inside dist < 1 (:32)
+                    sf = sf + f32(1)
+                    sv = sv + f32(1) * old_v[k]
                 s = f32(0.5) - dist
                 inv = f32(np.float64(1.0) / np.float64(dist))   # `a *= 1. / b` (dtypes.cuh:204-208)
                 acc = acc + (r * s) * inv
         F[i] = own + acc if by_plane else acc
+        if old_v is not None:
+            if by_plane:
+                sv, sf = sv_own + sv, sf_own + sf
+            if sf > 0:                                          # add_rhs, :155-159
+                F[i] = F[i] + sv / sf
     return F
 
 
@@ -89,6 +103,40 @@ def test_oracle_sums_as_the_reference_thread_does(oracle, sum_order):
     got = forces_of(oracle, X, sum_order)
     assert np.abs(F).max() > 1 and (F[-1] == 0).all()
     assert np.array_equal(F.view(np.uint32), got.view(np.uint32))
+
+
+def rhs_with_friction(lib, X, sum_order):
+    """Two steps: a real one (dt = 0.05: positions move, old_v becomes the mean right-hand side), then one with
+    dt = 0 whose old_v is the stage's right-hand side F + sum_v / sum_friction of the state in between."""
+    n = len(X)
+    with Solution("springs_grid", n, GS, 1.0, lib=lib) as s:
+        s.h_X[:n] = X
+        s.h_n = n
+        s.copy_to_device()
+        if sum_order:
+            s.set_param("sum_order", sum_order)
+        s.set_fixed(n - 1)
+        s.take_step(0.05, 1)
+        X1, v1 = s.positions().copy(), s.old_v()[:n].copy()
+        s.take_step(0.0, 1)
+        return X1, v1, s.old_v()[:n].copy()
+
+
+@pytest.mark.parametrize("sum_order", [0, 1])
+def test_oracle_friction_sums_in_the_reference_order(oracle, sum_order):
+    """The friction mean too: sum_v and sum_friction are accumulated in the same loop as F (solvers.cuh:453-458)."""
+    X1, v1, got = rhs_with_friction(oracle, system(), sum_order)
+    assert np.abs(v1).max() > 0.1 and (v1[-1] == 0).all()
+    want = reference_forces(X1, bool(sum_order), old_v=v1)
+    assert np.array_equal(want.view(np.uint32), got.view(np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sum_order", [0, 1])
+def test_engine_friction_sums_in_the_reference_order(device, sum_order):
+    X1, v1, got = rhs_with_friction(device, system(), sum_order)
+    want = reference_forces(X1, bool(sum_order), old_v=v1)
+    assert np.array_equal(want.view(np.uint32), got.view(np.uint32))
 
 
 def test_the_two_orders_are_different_roundings_of_the_same_sum(oracle):
