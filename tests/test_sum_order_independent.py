@@ -166,3 +166,50 @@ def test_engine_sums_as_the_reference_thread_does(device, sum_order):
             s.take_step(0.0, 1)
             got = s.old_v()[:n].copy()
         assert np.array_equal(F.view(np.uint32), got.view(np.uint32)), variant
+
+
+# ---- Tile_solver: all pairs, j ascending (solvers.cuh:284-322) ---------------------------------------------------
+def reference_tile_rhs(X):
+    """compute_tile's thread: for j = 0 .. n - 1 in order, no cut-off, the functor called for every pair; then the
+    fixed point's right-hand side subtracted (the lone cell is attracted by everybody here: its force is not 0)."""
+    n = len(X)
+    F = np.zeros((n, 3), f32)
+    for i in range(n):
+        acc = np.zeros(3, f32)
+        for k in range(n):
+            if k == i:
+                continue
+            r = X[i] - X[k]
+            dist = np.sqrt(fma32(r[2], r[2], fma32(r[1], r[1], f32(r[0] * r[0]))))
+            s = f32(0.5) - dist
+            inv = f32(np.float64(1.0) / np.float64(dist))
+            acc = acc + (r * s) * inv
+        F[i] = acc
+    return F - F[-1]          # euler_step / heun_step: dX.xyz -= fix.xyz, fix = dX[fix_point] (solvers.cuh:118-120,250-253)
+
+
+def tile_rhs_of(lib, X, lanes=None):
+    n = len(X)
+    with Solution("springs_tile", n, GS, 1.0, lib=lib) as s:
+        s.h_X[:n] = X
+        s.h_n = n
+        s.copy_to_device()
+        if lanes is not None:
+            s.set_param("tile_lanes", lanes)
+        s.set_fixed(n - 1)
+        s.take_step(0.0, 1)
+        return s.old_v()[:n].copy()
+
+
+def test_oracle_tile_sums_in_ascending_j(oracle):
+    X = system(n=150)
+    assert np.array_equal(reference_tile_rhs(X).view(np.uint32), tile_rhs_of(oracle, X).view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_engine_tile_sums_in_ascending_j(device):
+    """ya::tile_force (one thread per cell) and ya::tile_force_coop (16 / 64 lanes per cell): the reference's order."""
+    X = system(n=150)
+    want = reference_tile_rhs(X)
+    for lanes in (1, 16, 64, 0):
+        assert np.array_equal(want.view(np.uint32), tile_rhs_of(device, X, lanes).view(np.uint32)), lanes
