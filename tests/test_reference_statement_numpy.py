@@ -1,4 +1,8 @@
-"""An INDEPENDENT binary32 statement of the reference's grid-force sum, written in numpy from the reference alone
+"""An INDEPENDENT binary32 statement of the reference's step, written in numpy from the reference alone -- first the
+grid-force sum, then (further down) compute_tile's sum and whole Heun steps of Tile_solver and Grid_solver -- each held
+BIT FOR BIT against the oracle (CPU) and against the HIP engine (GPU tests), no tolerance anywhere.
+
+The grid-force sum
 (include/solvers.cuh:430-463 `compute_cube`, :472-483 the stencil table, :349-365 the cube id; examples/springs.cu:14-21
 the functor; include/dtypes.cuh:150-217 the operators) -- one running sum per cell over the 27 cubes in d_nhood
 order, cells of a cube in ascending id -- held bit for bit against
@@ -213,3 +217,129 @@ def test_engine_tile_sums_in_ascending_j(device):
     want = reference_tile_rhs(X)
     for lanes in (1, 16, 64, 0):
         assert np.array_equal(want.view(np.uint32), tile_rhs_of(device, X, lanes).view(np.uint32)), lanes
+
+
+# ---- the whole step, binary32, operation by operation (solvers.cuh:113-161, 226-275, 284-322) ----------------------
+def reference_tile_steps(X, steps, dt, p):
+    """Heun_solver::take_step with Tile_computer, friction_w_neighbour and set_fixed(p), in numpy binary32: the
+    stage's right-hand side F + sum_v / sum_friction (compute_tile j ascending, add_rhs), fix = dX[p], euler_step,
+    the second stage on X1 with the SAME old_v, heun_step.  Returns (X, old_v) after `steps` steps."""
+    n = len(X)
+    X = X.copy()
+    old_v = np.zeros((n, 3), f32)
+    dt = f32(dt)
+
+    def rhs(Y):
+        dX = np.zeros((n, 3), f32)
+        for i in range(n):
+            F, sv, sf = np.zeros(3, f32), np.zeros(3, f32), f32(0)
+            for k in range(n):
+                r = Y[i] - Y[k]
+                dist = np.sqrt(fma32(r[2], r[2], fma32(r[1], r[1], f32(r[0] * r[0]))))
+                if k != i:                                        # springs.cu:17 / solvers.cuh:30
+                    F = F + (r * (f32(0.5) - dist)) * f32(np.float64(1.0) / np.float64(dist))
+                    if dist < f32(1.0):                           # friction_w_neighbour: 1, else 0 (0 * v adds nothing)
+                        sf = sf + f32(1)
+                        sv = sv + old_v[k]
+            dX[i] = F                                             # d_dX[i] += F on a zero-filled array
+            if sf > 0:
+                dX[i] = dX[i] + sv / sf                           # add_rhs
+        return dX
+
+    for _ in range(steps):
+        dX = rhs(X)
+        dX = dX - dX[p]                                           # euler_step: d_dX[i].xyz -= fix_dX.xyz
+        X1 = X + dX * dt
+        dX1 = rhs(X1)
+        dX1 = dX1 - dX1[p]                                        # heun_step
+        X = X + ((dX + dX1) * f32(0.5)) * dt
+        old_v = (dX + dX1) * f32(0.5)
+    return X, old_v
+
+
+def tile_steps_of(lib, X, steps, dt, p, lanes=None):
+    n = len(X)
+    with Solution("springs_tile", n, GS, 1.0, lib=lib) as s:
+        s.h_X[:n] = X
+        s.h_n = n
+        s.copy_to_device()
+        if lanes is not None:
+            s.set_param("tile_lanes", lanes)
+        s.set_fixed(p)
+        s.take_step(dt, steps)
+        return s.positions().copy(), s.old_v()[:n].copy()
+
+
+def test_oracle_takes_the_reference_step_bit_for_bit(oracle):
+    """Three whole Heun steps (both stages average the neighbours' old velocities from the second step on)."""
+    X = system(n=90)
+    Xw, vw = reference_tile_steps(X, 3, 0.05, 7)
+    Xo, vo = tile_steps_of(oracle, X, 3, 0.05, 7)
+    assert np.abs(Xw - X).max() > 1e-2
+    assert np.array_equal(Xw.view(np.uint32), Xo.view(np.uint32))
+    assert np.array_equal(vw.view(np.uint32), vo.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_engine_takes_the_reference_step_bit_for_bit(device):
+    X = system(n=90)
+    Xw, vw = reference_tile_steps(X, 3, 0.05, 7)
+    for lanes in (1, 0):
+        Xd, vd = tile_steps_of(device, X, 3, 0.05, 7, lanes)
+        assert np.array_equal(Xw.view(np.uint32), Xd.view(np.uint32)), lanes
+        assert np.array_equal(vw.view(np.uint32), vd.view(np.uint32)), lanes
+
+
+def reference_grid_steps(X, steps, dt, p, by_plane):
+    """The same step with Grid_computer (solvers.cuh:430-463; the grid rebuilt from X and from X1)."""
+    n = len(X)
+    X = X.copy()
+    old_v = np.zeros((n, 3), f32)
+    dt = f32(dt)
+    for _ in range(steps):
+        dX = reference_forces(X, by_plane, old_v=old_v)
+        dX = dX - dX[p]
+        X1 = X + dX * dt
+        dX1 = reference_forces(X1, by_plane, old_v=old_v)
+        dX1 = dX1 - dX1[p]
+        X = X + ((dX + dX1) * f32(0.5)) * dt
+        old_v = (dX + dX1) * f32(0.5)
+    return X, old_v
+
+
+def grid_steps_of(lib, X, steps, dt, p, sum_order, variant=None):
+    n = len(X)
+    with Solution("springs_grid", n, GS, 1.0, lib=lib) as s:
+        s.h_X[:n] = X
+        s.h_n = n
+        s.copy_to_device()
+        if sum_order:
+            s.set_param("sum_order", sum_order)
+        if variant is not None:
+            s.set_param("force_variant", variant)
+        s.set_fixed(p)
+        s.take_step(dt, steps)
+        return s.positions().copy(), s.old_v()[:n].copy()
+
+
+@pytest.mark.parametrize("sum_order", [0, 1])
+def test_oracle_takes_the_reference_grid_step_bit_for_bit(oracle, sum_order):
+    X = system(n=200)
+    Xw, vw = reference_grid_steps(X, 3, 0.05, 199, bool(sum_order))
+    Xo, vo = grid_steps_of(oracle, X, 3, 0.05, 199, sum_order)
+    assert np.abs(Xw - X).max() > 1e-2
+    assert np.array_equal(Xw.view(np.uint32), Xo.view(np.uint32))
+    assert np.array_equal(vw.view(np.uint32), vo.view(np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sum_order", [0, 1])
+def test_engine_takes_the_reference_grid_step_bit_for_bit(device, sum_order):
+    """Three Heun steps on the grid -- two builds per step, the sorted-space second stage, the fused update kernels --
+    against numpy: the engine's bits ARE the reference's statement's."""
+    X = system(n=200)
+    Xw, vw = reference_grid_steps(X, 3, 0.05, 199, bool(sum_order))
+    for variant in (-1, 2, 3):
+        Xd, vd = grid_steps_of(device, X, 3, 0.05, 199, sum_order, variant)
+        assert np.array_equal(Xw.view(np.uint32), Xd.view(np.uint32)), variant
+        assert np.array_equal(vw.view(np.uint32), vd.view(np.uint32)), variant
