@@ -39,19 +39,19 @@ def system(n=260, seed=3):
     return X
 
 
-def reference_forces(X, by_plane, old_v=None):
+def reference_forces(X, by_plane, old_v=None, gs=GS):
     """F[i] exactly as the reference's thread accumulates it (or in the two partial sums of YA_SUM_BY_PLANE).
     With old_v: the stage's whole right-hand side, F + sum_v / sum_friction (solvers.cuh:453-461 and add_rhs
     :146-161) -- sum_friction += friction and sum_v += friction * old_v[k] run in the same loop, the same order."""
     n = len(X)
-    cube3 = np.floor(X).astype(np.int64) + GS // 2             # cube_size 1 (solvers.cuh:357-360; exact below 2^24)
-    cube = cube3[:, 0] + cube3[:, 1] * GS + cube3[:, 2] * GS * GS
+    cube3 = np.floor(X).astype(np.int64) + gs // 2             # cube_size 1 (solvers.cuh:357-360; exact below 2^24)
+    cube = cube3[:, 0] + cube3[:, 1] * gs + cube3[:, 2] * gs * gs
     members = {}
     for i in np.argsort(cube, kind="stable"):                  # stable sort: ascending id inside a cube
         members.setdefault(int(cube[i]), []).append(int(i))
     h = [-1, 0, 1]                                             # solvers.cuh:472-483
-    h = h + [h[i % 3] - GS for i in range(3)] + [h[i % 3] + GS for i in range(3)]
-    h = h + [h[i % 9] - GS * GS for i in range(9)] + [h[i % 9] + GS * GS for i in range(9)]
+    h = h + [h[i % 3] - gs for i in range(3)] + [h[i % 3] + gs for i in range(3)]
+    h = h + [h[i % 9] - gs * gs for i in range(9)] + [h[i % 9] + gs * gs for i in range(9)]
     F = np.zeros((n, 3), f32)
     for i in range(n):
         acc = np.zeros(3, f32)
@@ -343,3 +343,76 @@ def test_engine_takes_the_reference_grid_step_bit_for_bit(device, sum_order):
         Xd, vd = grid_steps_of(device, X, 3, 0.05, 199, sum_order, variant)
         assert np.array_equal(Xw.view(np.uint32), Xd.view(np.uint32)), variant
         assert np.array_equal(vw.view(np.uint32), vd.view(np.uint32)), variant
+
+
+# ---- the golden fixtures themselves, from numpy (set_fixed(): the centre of mass is held) --------------------------
+def fold256(lanes):
+    """lane[t] += lane[t + s] for s = 128 ... 1 (yalla_amd/csrc/core.hip fold256)."""
+    lanes = lanes.copy()
+    s2 = 128
+    while s2 >= 1:
+        lanes[:s2] = lanes[:s2] + lanes[s2:2 * s2]
+        s2 //= 2
+    return lanes[0]
+
+
+def tree_sum(v):
+    """The engine's documented order for the centre-of-mass sum: B = clamp(ceil(n / 256), 1, 1024) blocks x 256 lanes;
+    lane (b, t) sums rows 256 b + t, + 256 B, ... serially from 0; each block folds its lanes by halving; one block
+    then sums the B partial sums the same way."""
+    n, w = v.shape
+    B = min(max((n + 255) // 256, 1), 1024)
+    partials = np.zeros((B, w), f32)
+    for b in range(B):
+        lanes = np.zeros((256, w), f32)
+        for t in range(256):
+            for i in range(b * 256 + t, n, B * 256):
+                lanes[t] = lanes[t] + v[i]
+        partials[b] = fold256(lanes)
+    lanes = np.zeros((256, w), f32)
+    for t in range(256):
+        for q in range(t, B, 256):
+            lanes[t] = lanes[t] + partials[q]
+    return fold256(lanes)
+
+
+def serial_sum(v):
+    acc = np.zeros(v.shape[1], f32)          # thrust::reduce(first, last, Pt{0}) read left to right (solvers.cuh:242)
+    for row in v:
+        acc = acc + row
+    return acc
+
+
+def golden_steps(X, steps, dt, gs, by_plane, reduce):
+    n = len(X)
+    X = X.copy()
+    old_v = np.zeros((n, 3), f32)
+    dt = f32(dt)
+    inv_n = f32(np.float64(1.0) / np.float64(f32(n)))          # Pt / n == Pt * float(1. / n)  (dtypes.cuh:202-208)
+    for _ in range(steps):
+        dX = reference_forces(X, by_plane, old_v=old_v, gs=gs)
+        dX = dX - reduce(dX) * inv_n                            # :241-242, euler_step
+        X1 = X + dX * dt
+        dX1 = reference_forces(X1, by_plane, old_v=old_v, gs=gs)
+        dX1 = dX1 - reduce(dX1) * inv_n                         # :268, heun_step
+        X = X + ((dX + dX1) * f32(0.5)) * dt
+        old_v = (dX + dX1) * f32(0.5)
+    return X, old_v
+
+
+@pytest.mark.parametrize("name", ["springs_grid_n50", "springs_grid_n800"])
+def test_golden_fixture_from_numpy(name):
+    """tests/golden/springs_grid_n50.npz / _n800.npz (written by the ORACLE, tests/golden/make_golden.py) recomputed
+    from their stored inputs by the numpy statement of the reference: X (reference sum, the engine's centre-of-mass
+    tree: one block at 50 cells, four and a second level at 800), X_serial_reduce (all of the reference's defaults)
+    and X_by_plane, bit for bit."""
+    import os
+    ref = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+    X0 = ref["X0"]
+    X, v = golden_steps(X0, 2, 0.001, 50, False, tree_sum)
+    assert np.array_equal(X.view(np.uint32), ref["X"].view(np.uint32))
+    assert np.array_equal(v.view(np.uint32), ref["old_v"].view(np.uint32))
+    Xs, _ = golden_steps(X0, 2, 0.001, 50, False, serial_sum)
+    assert np.array_equal(Xs.view(np.uint32), ref["X_serial_reduce"].view(np.uint32))
+    Xp, _ = golden_steps(X0, 2, 0.001, 50, True, tree_sum)
+    assert np.array_equal(Xp.view(np.uint32), ref["X_by_plane"].view(np.uint32))
