@@ -39,7 +39,7 @@ def system(n=260, seed=3):
     return X
 
 
-def reference_forces(X, by_plane, old_v=None, gs=GS):
+def reference_forces(X, by_plane, old_v=None, gs=GS, functor="spring"):
     """F[i] exactly as the reference's thread accumulates it (or in the two partial sums of YA_SUM_BY_PLANE).
     With old_v: the stage's whole right-hand side, F + sum_v / sum_friction (solvers.cuh:453-461 and add_rhs
     :146-161) -- sum_friction += friction and sum_v += friction * old_v[k] run in the same loop, the same order."""
@@ -74,9 +74,13 @@ def reference_forces(X, by_plane, old_v=None, gs=GS):
                 if old_v is not None:                           # friction_w_neighbour: 1 inside dist < 1 (:32)
                     sf = sf + f32(1)
                     sv = sv + f32(1) * old_v[k]
-                s = f32(0.5) - dist
-                inv = f32(np.float64(1.0) / np.float64(dist))   # `a *= 1. / b` (dtypes.cuh:204-208)
-                acc = acc + (r * s) * inv
+                if functor == "spring":
+                    s = f32(0.5) - dist
+                    inv = f32(np.float64(1.0) / np.float64(dist))   # `a *= 1. / b` (dtypes.cuh:204-208)
+                    acc = acc + (r * s) * inv
+                else:   # relu_force, inits.cuh:78-93: scalar float arithmetic, a true division per component
+                    Fm = np.maximum(f32(0.8) - dist, f32(0)) * f32(2) - np.maximum(dist - f32(0.8), f32(0))
+                    acc = acc + (r * Fm) / dist
         F[i] = own + acc if by_plane else acc
         if old_v is not None:
             if by_plane:
@@ -383,17 +387,17 @@ def serial_sum(v):
     return acc
 
 
-def golden_steps(X, steps, dt, gs, by_plane, reduce):
+def golden_steps(X, steps, dt, gs, by_plane, reduce, functor="spring"):
     n = len(X)
-    X = X.copy()
+    X = X[:, :3].copy()     # (further fields of a wider point get no force from these functors and stay as they are)
     old_v = np.zeros((n, 3), f32)
     dt = f32(dt)
     inv_n = f32(np.float64(1.0) / np.float64(f32(n)))          # Pt / n == Pt * float(1. / n)  (dtypes.cuh:202-208)
     for _ in range(steps):
-        dX = reference_forces(X, by_plane, old_v=old_v, gs=gs)
+        dX = reference_forces(X, by_plane, old_v=old_v, gs=gs, functor=functor)
         dX = dX - reduce(dX) * inv_n                            # :241-242, euler_step
         X1 = X + dX * dt
-        dX1 = reference_forces(X1, by_plane, old_v=old_v, gs=gs)
+        dX1 = reference_forces(X1, by_plane, old_v=old_v, gs=gs, functor=functor)
         dX1 = dX1 - reduce(dX1) * inv_n                         # :268, heun_step
         X = X + ((dX + dX1) * f32(0.5)) * dt
         old_v = (dX + dX1) * f32(0.5)
@@ -416,3 +420,17 @@ def test_golden_fixture_from_numpy(name):
     assert np.array_equal(Xs.view(np.uint32), ref["X_serial_reduce"].view(np.uint32))
     Xp, _ = golden_steps(X0, 2, 0.001, 50, True, tree_sum)
     assert np.array_equal(Xp.view(np.uint32), ref["X_by_plane"].view(np.uint32))
+
+
+def test_golden_fixture_of_five_float_points_from_numpy():
+    """tests/golden/relu_po_grid_n250.npz: relu_force (inits.cuh:78-93) on Po_cell {x, y, z, theta, phi}, five steps
+    of dt 0.1 -- positions and velocities from numpy, the polarity fields untouched."""
+    import os
+    ref = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "relu_po_grid_n250.npz"))
+    X0 = ref["X0"]
+    X, v = golden_steps(X0, 5, 0.1, 50, False, tree_sum, functor="relu")
+    assert np.array_equal(X.view(np.uint32), ref["X"][:, :3].copy().view(np.uint32))
+    assert np.array_equal(v.view(np.uint32), ref["old_v"].view(np.uint32))
+    assert np.array_equal(ref["X"][:, 3:].view(np.uint32), X0[:, 3:].view(np.uint32))
+    Xp, _ = golden_steps(X0, 5, 0.1, 50, True, tree_sum, functor="relu")
+    assert np.array_equal(Xp.view(np.uint32), ref["X_by_plane"][:, :3].copy().view(np.uint32))
