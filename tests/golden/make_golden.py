@@ -14,6 +14,10 @@ What is stored per case:
   X_serial_reduce   the same with the serial centre-of-mass sum: the oracle's all-defaults reading of the reference
   X_by_plane        grid cases: the engine's OPT-IN own-plane | other-planes order (YA_SUM_BY_PLANE), tree COM
 
+Three of the fixtures are ALSO recomputed from their stored inputs by an independent numpy binary32 statement of the
+reference (tests/test_reference_statement_numpy.py: springs_grid_n50, springs_grid_n800, relu_po_grid_n250 -- X, old_v,
+X_serial_reduce, X_by_plane bit for bit), so those are pinned by more than the oracle that wrote them.
+
 clipped_grid_n4096_100steps pins nothing physical: springs + friction_w_neighbour are chaotic over 100 steps (the
 tree and the serial COM order alone move every cell by ~1.4, 148 % of the system's extent; so do the two grid
 summation orders).  It is a BIT-REGRESSION fixture only -- same order, same bits -- which is why the cross-order
