@@ -227,8 +227,8 @@ def kernel_source_sha():
 
 def counters_key(args, n_total):
     """Key of this workload in profiles/r06_counters.json (None: no counters kept for it)."""
-    if args.slab or args.gpus > 1 or args.force_variant not in (-1, 2):
-        return None
+    if args.slab or args.gpus > 1 or args.force_variant not in (-1, 2) or args.sum_order != 0:
+        return None   # (the counters on file were taken on the default kernel choice and summation order)
     tier = "" if args.arith == "exact" else "_fast"
     if args.model == "springs_grid" and args.dist == 0.5 and n_total in (1_000_000, 10_000_000):
         return ("springs_1M" if n_total == 1_000_000 else "springs_10M") + tier
