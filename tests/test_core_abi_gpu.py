@@ -138,6 +138,43 @@ def test_grid_build_with_changing_population(hip):
     hip.ya_grid_destroy(g)
 
 
+def test_count_published_by_the_binning_kernel(hip):
+    """ya_grid_build_sorted_begin_publish (round 6): the first build of a step bins with the count read on the
+    device AND hands that count to the host itself -- ya_n_read_end returns it without a copy in the stream -- for a
+    population that changes between builds (proliferation), n = 0 included; _finish then gives numpy's arrays."""
+    n_max, gs, cs = 20000, 32, 1.0
+    vp, i32, f32c, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+    hip.ya_n_reader_create.argtypes = [C.POINTER(vp)]
+    hip.ya_n_reader_destroy.argtypes = [vp]
+    hip.ya_n_read_end.argtypes = [vp, C.POINTER(i32)]
+    hip.ya_grid_build_sorted_begin_publish.argtypes = [vp, vp, sz, vp, i32, f32c, vp, vp]
+    hip.ya_grid_build_sorted_finish.argtypes = [vp, vp, sz, vp, i32, vp, sz, vp, vp]
+    rng = np.random.default_rng(11)
+    X = ((rng.random((n_max, 3), dtype=np.float32) - 0.5) * np.float32(gs - 3)).astype(np.float32)
+    dX, dv = Dev(hip, X), Dev(hip, np.zeros((n_max, 3), np.float32))
+    sorted_X, sorted_v = Dev(hip, nbytes=n_max * 16), Dev(hip, nbytes=n_max * 16)
+    g, reader = vp(), vp()
+    assert hip.ya_grid_create(n_max, gs, C.byref(g)) == 0 and hip.ya_n_reader_create(C.byref(reader)) == 0
+    ptrs = [vp() for _ in range(4)]
+    hip.ya_grid_arrays(g, *[C.byref(q) for q in ptrs])
+    for n in (12000, 12001, 15000, 20000, 300, 0, 7777):
+        d_n = Dev(hip, np.array([n], np.int32))
+        assert hip.ya_grid_build_sorted_begin_publish(g, dX.p, 12, d_n.p, n_max, cs, reader, None) == 0
+        got = i32(-1)
+        assert hip.ya_n_read_end(reader, C.byref(got)) == 0 and got.value == n
+        if n == 0:
+            continue
+        assert hip.ya_grid_build_sorted_finish(g, dX.p, 12, dv.p, n, sorted_X.p, 16, sorted_v.p, None) == 0
+        hip.ya_device_synchronize()
+        ref = numpy_grid(X[:n], cs, gs)
+        for name, a, q, count in zip(("cube_id", "point_id", "cube_start", "cube_end"), ref, ptrs, (n, n, gs ** 3, gs ** 3)):
+            out = np.empty(count, np.int32)
+            hip.ya_memcpy_d2h(out.ctypes.data, q, out.nbytes)
+            assert np.array_equal(a, out), (name, n)
+    hip.ya_n_reader_destroy(reader)
+    hip.ya_grid_destroy(g)
+
+
 @pytest.mark.parametrize("point_f,entry_f", [(3, 4), (4, 8), (5, 6)])
 def test_rebuild_from_sorted_cells_equals_build_from_original_order(hip, point_f, entry_f):
     """ya_grid_rebuild_sorted (second Heun stage): cells that sit in an earlier build's
